@@ -1,0 +1,123 @@
+// common.h — shared device helpers for the gfx950 kernels (wave64, bf16 storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cambrian_amd.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+#define CMB_WAVE 64
+
+#define CMB_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return CMB_ERR_LAUNCH;            \
+  } while (0)
+
+static inline bool cmb_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- rowmap -------------------------------------------------------------------------------
+struct RowMap {
+  uint32_t n1, n2;
+  int64_t s0, s1, s2;
+};
+static inline RowMap make_rowmap(const cmb_rowmap& m) {
+  RowMap r;
+  r.n1 = (uint32_t)m.n1; r.n2 = (uint32_t)(m.n2 ? m.n2 : 1);
+  r.s0 = m.s0; r.s1 = m.s1; r.s2 = m.s2;
+  return r;
+}
+__host__ __device__ static inline int64_t row_off(const RowMap& m, uint32_t r) {
+  if (m.n1 == 0) return (int64_t)r * m.s2;
+  uint32_t a = r / m.n1, rem = r - a * m.n1;
+  uint32_t b = rem / m.n2, c = rem - b * m.n2;
+  return (int64_t)a * m.s0 + (int64_t)b * m.s1 + (int64_t)c * m.s2;
+}
+
+// ---- 8-element vector load/store with fp32 math ------------------------------------------------
+// A "vec8" is 8 consecutive elements: 16 bytes of bf16 or 32 bytes of fp32.
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    bf16x8_t x = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8_t x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8_t*>(p) = x;
+  }
+};
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+    f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    f32x4_t a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4_t*>(p) = a;
+    *reinterpret_cast<f32x4_t*>(p + 4) = b;
+  }
+};
+
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) { Vec8<float>::load(p, v); }
+
+// ---- wave reductions (64 lanes) ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activations (fp32) -------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(int act, float x) {
+  switch (act) {
+    case CMB_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case CMB_ACT_GELU_TANH: {
+      const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+      return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+    }
+    case CMB_ACT_QUICK_GELU: return x / (1.0f + expf(-1.702f * x));
+    case CMB_ACT_SILU: return x / (1.0f + expf(-x));
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+  switch (act) {
+    case CMB_ACT_GELU_ERF: {
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case CMB_ACT_GELU_TANH: {
+      const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+      const float u = k0 * (x + k1 * x * x * x);
+      const float t = tanhf(u);
+      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x * x);
+    }
+    case CMB_ACT_QUICK_GELU: {
+      const float s = 1.0f / (1.0f + expf(-1.702f * x));
+      return s + 1.702f * x * s * (1.0f - s);
+    }
+    case CMB_ACT_SILU: {
+      const float s = 1.0f / (1.0f + expf(-x));
+      return s + x * s * (1.0f - s);
+    }
+    default: return 1.0f;
+  }
+}

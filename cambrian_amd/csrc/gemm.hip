@@ -1,0 +1,367 @@
+// gemm.hip — C[M,N] = epilogue(alpha * A[M,K] · B[N,K]^T) for gfx950 (MI355X).
+//
+// Design:
+//   * operands stream HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS stages,
+//     one barrier per 128-byte K-step; the next K-step's DMA is issued before the current MFMAs.
+//   * LDS tiles are XOR-swizzled (gemm_layout.h) so every ds_read_b128 fragment read is
+//     bank-conflict free; the swizzle lives in the per-lane global source address.
+//   * v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact fp32 parity path),
+//     fp32 accumulation in 64 accumulator registers per wave (2x2 tiles of 32x32).
+//   * operands are swapped at the MFMA so a lane owns one output row and 4 consecutive columns per
+//     register quad; the tile is staged through LDS once and leaves as 16/32-byte row-contiguous
+//     stores with the whole epilogue (bias, activation, LayerScale, residual, fp32 accumulate) fused.
+//   * block id -> tile mapping is XCD-aware (8 XCDs, private L2s).
+//   * rows of A / C / residual / pre_out go through a 3-level row map so gathers such as the in-LLM
+//     slice hidden[:, 91:691].view(B,24,25,H)[:, :, :24] are folded into the loads.
+#include "common.h"
+#include "gemm_layout.h"
+
+namespace {
+
+struct GemmParams {
+  int M, N, K;
+  const char* A; RowMap a_map;
+  const char* B; int64_t ldb;
+  char* C; RowMap c_map;
+  const float* bias;
+  const float* colscale;
+  const char* R; RowMap r_map;
+  char* P; RowMap p_map;
+  int act;
+  float alpha, beta;
+  int out_f32;
+  int tiles_m, tiles_n;
+  int k_per_split;
+  float* slabs;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  typedef bf16x8_t frag_t;
+  static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<float> {
+  typedef f32x4_t frag_t;
+  static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int BM, int BN>
+constexpr int gemm_smem_bytes() {
+  return (2 * (BM + BN) * 128) > (BM * (BN + 4) * 4) ? (2 * (BM + BN) * 128) : (BM * (BN + 4) * 4);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  constexpr int BK = 128 / (int)sizeof(T);
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+  typedef typename Mfma<T>::frag_t frag_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int id = gl_xcd_remap((int)blockIdx.x, nblk);
+  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kz = blockIdx.y;
+  const int kbeg = kz * p.k_per_split;
+  const int kend = (kbeg + p.k_per_split < p.K) ? (kbeg + p.k_per_split) : p.K;
+  const int nk = (kend > kbeg) ? (kend - kbeg) / BK : 0;
+
+  // per-lane global source pointers of the LDS-DMA pieces this wave issues (row clamped at the edge:
+  // out-of-range rows re-read the last valid row and are never stored)
+  const char* a_src[A_IT];
+  const char* b_src[B_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int grp = wave + i * NW;
+    const int row = gl_dma_row(grp, lane), c = gl_dma_chunk(grp, lane);
+    int gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    a_src[i] = p.A + (row_off(p.a_map, (uint32_t)gm) + kbeg) * (int64_t)sizeof(T) + c * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int grp = wave + i * NW;
+    const int row = gl_dma_row(grp, lane), c = gl_dma_chunk(grp, lane);
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    b_src[i] = p.B + ((int64_t)gn * p.ldb + kbeg) * (int64_t)sizeof(T) + c * 16;
+  }
+
+  // fragment read offsets (bytes inside a stage)
+  int a_off[TM], a_swz[TM], b_off[TN], b_swz[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * 32 + gl_frag_row(lane);
+    a_off[t] = row * 128;
+    a_swz[t] = gl_swz(row);
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * WTN + t * 32 + gl_frag_row(lane);
+    b_off[t] = A_BYTES + row * 128;
+    b_swz[t] = gl_swz(row);
+  }
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto stage = [&](int s) {
+    char* sa = smem + s * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      glds16(a_src[i], sa + (wave + i * NW) * 1024);
+      a_src[i] += 128;
+    }
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      glds16(b_src[i], sb + (wave + i * NW) * 1024);
+      b_src[i] += 128;
+    }
+  };
+
+  if (nk > 0) {
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1);  // async: lands while this K-step's MFMAs run
+      const char* base = smem + cur * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        frag_t a[TM], b[TN];
+        const int ch = gl_frag_chunk(ks, lane);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          a[t] = *reinterpret_cast<const frag_t*>(base + a_off[t] + ((ch ^ a_swz[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          b[t] = *reinterpret_cast<const frag_t*>(base + b_off[t] + ((ch ^ b_swz[t]) << 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mfma<T>::run(b[j], a[i], acc[i][j]);  // swapped: rows=n, cols=m
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32, row stride BN+4) -> row-contiguous global stores ----
+  constexpr int CS = BN + 4;
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = wm * WTM + i * 32 + gl_acc_m(lane);
+        const int n = wn * WTN + j * 32 + gl_acc_n(4 * q, lane);
+        f32x4_t v;
+        v[0] = acc[i][j][4 * q + 0];
+        v[1] = acc[i][j][4 * q + 1];
+        v[2] = acc[i][j][4 * q + 2];
+        v[3] = acc[i][j][4 * q + 3];
+        *reinterpret_cast<f32x4_t*>(cs + m * CS + n) = v;
+      }
+  __syncthreads();
+
+  constexpr int GPR = BN / 8;  // 8-column groups per tile row
+  constexpr int GROUPS = BM * GPR;
+  for (int grp = tid; grp < GROUPS; grp += NT) {
+    const int row = grp / GPR, c8 = grp - row * GPR;
+    const int gm = m0 + row, gn = n0 + c8 * 8;
+    if (gm >= p.M || gn >= p.N) continue;
+    float v[8];
+    {
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8);
+      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    }
+    if (p.slabs) {  // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
+      Vec8<float>::store(p.slabs + ((int64_t)kz * p.M + gm) * p.N + gn, v);
+      continue;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    if (p.bias) {
+      float bb[8];
+      load8f(p.bias + gn, bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bb[e];
+    }
+    if (p.P) Vec8<T>::store(reinterpret_cast<T*>(p.P) + row_off(p.p_map, (uint32_t)gm) + gn, v);
+    if (p.act != CMB_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_apply(p.act, v[e]);
+    }
+    if (p.colscale) {
+      float ss[8];
+      load8f(p.colscale + gn, ss);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= ss[e];
+    }
+    if (p.R) {
+      float rr[8];
+      Vec8<T>::load(reinterpret_cast<const T*>(p.R) + row_off(p.r_map, (uint32_t)gm) + gn, rr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rr[e];
+    }
+    const int64_t coff = row_off(p.c_map, (uint32_t)gm) + gn;
+    if (p.out_f32) {
+      float* cp = reinterpret_cast<float*>(p.C) + coff;
+      if (p.beta != 0.0f) {
+        float old[8];
+        load8f(cp, old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.beta * old[e];
+      }
+      Vec8<float>::store(cp, v);
+    } else {
+      Vec8<T>::store(reinterpret_cast<T*>(p.C) + coff, v);
+    }
+  }
+}
+
+// out = alpha * sum_z slab[z] + beta * out   (fp32 slabs [Z][M][N]; out through the C row map)
+template <typename TOut>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* slabs, int Z, int M, int N,
+                                                            char* C, RowMap c_map, float alpha,
+                                                            float beta) {
+  const int64_t groups = (int64_t)M * (N / 8);
+  for (int64_t gidx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gidx < groups;
+       gidx += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(gidx / (N / 8)), n = (int)(gidx - (int64_t)m * (N / 8)) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < Z; ++z) {
+      float v[8];
+      load8f(slabs + ((int64_t)z * M + m) * N + n, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    TOut* cp = reinterpret_cast<TOut*>(C) + row_off(c_map, (uint32_t)m) + n;
+    if (beta != 0.0f) {
+      float old[8];
+      Vec8<TOut>::load(cp, old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = alpha * acc[e] + beta * old[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+    }
+    Vec8<TOut>::store(cp, acc);
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_gemm(GemmParams& p, int splits, hipStream_t s) {
+  constexpr int smem = gemm_smem_bytes<BM, BN>();
+  static bool attr_done = false;
+  auto kern = gemm_nt_kernel<T, BM, BN, WM, WN>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return CMB_ERR_LAUNCH;
+    attr_done = true;
+  }
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, p);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+template <typename T>
+int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
+  constexpr int BK = 128 / (int)sizeof(T);
+  if (d->K % BK != 0 || d->N % 8 != 0) return CMB_ERR_SHAPE;
+  GemmParams p;
+  p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
+  p.A = (const char*)d->A; p.a_map = make_rowmap(d->a_map);
+  p.B = (const char*)d->B; p.ldb = d->ldb;
+  p.C = (char*)d->C; p.c_map = make_rowmap(d->c_map);
+  p.bias = d->bias; p.colscale = d->colscale;
+  p.R = (const char*)d->residual; p.r_map = make_rowmap(d->r_map);
+  p.P = (char*)d->pre_out; p.p_map = make_rowmap(d->p_map);
+  p.act = d->act; p.alpha = d->alpha; p.beta = d->beta;
+  p.out_f32 = (d->out_dtype == CMB_F32);
+  p.slabs = nullptr;
+  p.k_per_split = p.K;
+  int splits = d->split_k > 1 ? d->split_k : 1;
+  // every row base and leading dimension must keep 16-byte chunks aligned
+  const int64_t es = sizeof(T);
+  if (!cmb_aligned16(d->A) || !cmb_aligned16(d->B) || (d->ldb * es) % 16 != 0 ||
+      (d->a_map.s2 * es) % 16 != 0 || (d->a_map.n1 && ((d->a_map.s0 * es) % 16 || (d->a_map.s1 * es) % 16)))
+    return CMB_ERR_ALIGNMENT;
+  if (splits > 1) {
+    int ksteps = p.K / BK;
+    if (splits > ksteps) splits = ksteps;
+    int per = (ksteps + splits - 1) / splits;
+    splits = (ksteps + per - 1) / per;
+    p.k_per_split = per * BK;
+    if (splits > 1) {
+      const int64_t need = (int64_t)splits * p.M * p.N * 4;
+      if (!d->workspace || d->workspace_bytes < need) return CMB_ERR_WORKSPACE;
+      p.slabs = (float*)d->workspace;
+    } else {
+      p.k_per_split = p.K;
+    }
+  }
+  int rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+  if (rc != CMB_OK) return rc;
+  if (p.slabs) {
+    const int64_t groups = (int64_t)p.M * (p.N / 8);
+    int blocks = (int)((groups + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (p.out_f32)
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, p.slabs, splits,
+                         p.M, p.N, p.C, p.c_map, p.alpha, p.beta);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, p.slabs, splits, p.M,
+                         p.N, p.C, p.c_map, p.alpha, p.beta);
+    CMB_CHECK_LAUNCH();
+  }
+  return CMB_OK;
+}
+
+}  // namespace
+
+extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return CMB_ERR_BAD_ARG;
+  if (d->M < 0 || d->N <= 0 || d->K <= 0) return CMB_ERR_BAD_ARG;
+  if (d->M == 0) return CMB_OK;
+  if (d->dtype == CMB_F32 && d->out_dtype != CMB_F32) return CMB_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == CMB_BF16) return gemm_dispatch<bf16_t>(d, s);
+  if (d->dtype == CMB_F32) return gemm_dispatch<float>(d, s);
+  return CMB_ERR_BAD_ARG;
+}

@@ -1,0 +1,564 @@
+// norm.hip — LayerNorm / RMSNorm forward + backward and RoPE for gfx950.  All HBM-bound:
+// one wave (64 lanes) owns one row, 16-byte (bf16) / 32-byte (fp32) vector accesses, the row is
+// held in registers between the statistics pass and the normalisation pass (one HBM read, one
+// write per element), fp32 math throughout.
+#include "common.h"
+
+namespace {
+
+// token row -> window-local position on a side x side grid partitioned into grid_r x grid_r windows
+__device__ __forceinline__ int window_pos(uint32_t row, int side, int grid_r) {
+  const uint32_t t = row % (uint32_t)(side * side);
+  const uint32_t y = t / (uint32_t)side, x = t - y * (uint32_t)side;
+  return (int)((y % (uint32_t)grid_r) * (uint32_t)grid_r + (x % (uint32_t)grid_r));
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward.  NCH = vec8 chunks per lane (D <= NCH*512).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(
+    const T* __restrict__ x, int64_t rows, int D, int64_t ldx, const float* __restrict__ add, int side,
+    int grid_r, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    T* __restrict__ y, int64_t ldy, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nvec = D >> 3;
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    float v[NCH][8];
+    const T* xr = x + row * ldx;
+    const float* ar = add ? add + (int64_t)window_pos((uint32_t)row, side, grid_r) * D : nullptr;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        Vec8<T>::load(xr + vi * 8, v[c]);
+        if (ar) {
+          float a[8];
+          load8f(ar + vi * 8, a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[c][e] += a[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[c][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[c][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    T* yr = y + row * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
+        if (gamma) {
+          float gg[8], bb[8];
+          load8f(gamma + vi * 8, gg);
+          load8f(beta + vi * 8, bb);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = o[e] * gg[e] + bb[e];
+        }
+        Vec8<T>::store(yr + vi * 8, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  Rows are enumerated window-major so that all rows a block touches share one
+// position-table row: blockIdx.y = pos (0..grid_r^2-1), and "window" w enumerates
+// (b, qy, qx); token row = b*side^2 + (qy*grid_r+py)*side + qx*grid_r+px.  With grid_r == 1 this
+// is the identity enumeration.  Per-lane partial sums of dgamma / dbeta / dadd live in registers,
+// are combined across the block's 4 waves through LDS and leave as one atomicAdd per column per block.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TDx, int NCH, bool ACCUM>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(
+    const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, int64_t rows, int D,
+    const float* __restrict__ add, int side, int grid_r, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, TDx* __restrict__ dx,
+    int64_t lddx, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dadd) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* sred = reinterpret_cast<float*>(dyn_smem);  // [4 waves][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = D >> 3;
+  const int pos = blockIdx.y;
+  const int py = pos / grid_r, px = pos - py * grid_r;
+  const int qside = side / grid_r;
+  const int64_t nwin = rows / ((int64_t)grid_r * grid_r);  // windows (= rows when grid_r == 1)
+  const float* ar = add ? add + (int64_t)pos * D : nullptr;
+
+  float pg[NCH][8], pb[NCH][8], pa[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pg[c][e] = 0.f; pb[c][e] = 0.f; pa[c][e] = 0.f; }
+
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t w = wave_global; w < nwin; w += nwaves) {
+    int64_t row;
+    if (grid_r == 1) {
+      row = w;
+    } else {
+      const int64_t b = w / ((int64_t)qside * qside);
+      const int t = (int)(w - b * (int64_t)qside * qside);
+      const int qy = t / qside, qx = t - qy * qside;
+      row = b * (int64_t)side * side + (int64_t)(qy * grid_r + py) * side + (qx * grid_r + px);
+    }
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const T* xr = x + row * ldx;
+    const T* dyr = dy + row * lddy;
+    float xh[NCH][8], g[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float xv[8], dv[8];
+        Vec8<T>::load(xr + vi * 8, xv);
+        Vec8<T>::load(dyr + vi * 8, dv);
+        if (ar) {
+          float a[8];
+          load8f(ar + vi * 8, a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] += a[e];
+        }
+        float gg[8];
+        if (gamma) load8f(gamma + vi * 8, gg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[c][e] = (xv[e] - mean) * rstd;
+          if (gamma) {
+            pg[c][e] += dv[e] * xh[c][e];
+            pb[c][e] += dv[e];
+            g[c][e] = dv[e] * gg[e];
+          } else {
+            g[c][e] = dv[e];
+          }
+          s1 += g[c][e];
+          s2 += g[c][e] * xh[c][e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)D;
+    const float c2 = wave_sum(s2) / (float)D;
+    TDx* dxr = dx + row * lddx;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = (g[c][e] - c1 - xh[c][e] * c2) * rstd;
+          pa[c][e] += o[e];
+        }
+        if (ACCUM) {
+          float old[8];
+          Vec8<TDx>::load(dxr + vi * 8, old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        Vec8<TDx>::store(dxr + vi * 8, o);
+      }
+    }
+  }
+
+  // block-level combine of the partial sums, one quantity at a time through sred[4][D]
+  auto combine = [&](float (&part)[NCH][8], float* out) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sred[wave * D + vi * 8 + e] = part[c][e];
+      }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256) {
+      const float t = sred[col] + sred[D + col] + sred[2 * D + col] + sred[3 * D + col];
+      if (t != 0.f) atomicAdd(out + col, t);
+    }
+  };
+  if (gamma && dgamma) combine(pg, dgamma);
+  if (gamma && dbeta) combine(pb, dbeta);
+  if (ar && dadd) combine(pa, dadd + (int64_t)pos * D);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_fwd_kernel(const T* __restrict__ x, int64_t rows, int D,
+                                                          const float* __restrict__ w, float eps,
+                                                          T* __restrict__ y, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nvec = D >> 3;
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    float v[NCH][8];
+    const T* xr = x + row * (int64_t)D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        Vec8<T>::load(xr + vi * 8, v[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[c][e] * v[c][e];
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(s) / (float)D + eps);
+    T* yr = y + row * (int64_t)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float ww[8], o[8];
+        load8f(w + vi * 8, ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = ww[e] * (v[c][e] * rstd);
+        Vec8<T>::store(yr + vi * 8, o);
+      }
+    }
+    if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+  }
+}
+
+// Two passes over the row (the second one hits L2): keeps the register footprint independent of D so
+// that D = 4096 / 5120 / 7168 (Llama-3-8B / Vicuna-13B / Yi-34B) all run without spills.
+template <typename T, int NCH, bool HAS_DW>
+__global__ void __launch_bounds__(256) rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          int64_t rows, int D, const float* __restrict__ w,
+                                                          const float* __restrict__ rstd_in,
+                                                          T* __restrict__ dx, float* __restrict__ dw) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* sred = reinterpret_cast<float*>(dyn_smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nvec = D >> 3;
+  float pw[HAS_DW ? NCH : 1][8];
+#pragma unroll
+  for (int c = 0; c < (HAS_DW ? NCH : 1); ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pw[c][e] = 0.f;
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    const float rstd = rstd_in[row];
+    const T* xr = x + row * (int64_t)D;
+    const T* dyr = dy + row * (int64_t)D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float xv[8], dv[8], ww[8];
+        Vec8<T>::load(xr + vi * 8, xv);
+        Vec8<T>::load(dyr + vi * 8, dv);
+        load8f(w + vi * 8, ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = xv[e] * rstd;
+          if (HAS_DW) pw[HAS_DW ? c : 0][e] += dv[e] * xh;
+          s += dv[e] * ww[e] * xh;
+        }
+      }
+    }
+    const float c2 = wave_sum(s) / (float)D;
+    T* dxr = dx + row * (int64_t)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float xv[8], dv[8], ww[8], o[8];
+        Vec8<T>::load(xr + vi * 8, xv);
+        Vec8<T>::load(dyr + vi * 8, dv);
+        load8f(w + vi * 8, ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (dv[e] * ww[e] - xv[e] * rstd * c2) * rstd;
+        Vec8<T>::store(dxr + vi * 8, o);
+      }
+    }
+  }
+  if (HAS_DW) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sred[wave * D + vi * 8 + e] = pw[HAS_DW ? c : 0][e];
+      }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256) {
+      const float t = sred[col] + sred[D + col] + sred[2 * D + col] + sred[3 * D + col];
+      atomicAdd(dw + col, t);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE, rotate-half form.  The cos/sin table depends only on position_ids, so it is built once per
+// forward (rope_table_kernel) and shared by every decoder layer's q and k, forward and backward;
+// rope_apply_kernel is then a pure 16-byte-vectorised streaming pass (in place).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rope_table_kernel(const int64_t* __restrict__ pos_ids, int64_t ntok,
+                                                         int half, int Dh, float base,
+                                                         float* __restrict__ cos_t, float* __restrict__ sin_t) {
+  const int64_t n = ntok * half;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < n;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tok = idx / half;
+    const int i = (int)(idx - tok * half);
+    // inv_freq = 1 / base^(2i/Dh) in fp32, angle = pos * inv_freq (phi3/modeling_phi3.py:127-141)
+    const float inv_freq = 1.0f / powf(base, (float)(2 * i) / (float)Dh);
+    float sn, cs;
+    sincosf((float)pos_ids[tok] * inv_freq, &sn, &cs);
+    cos_t[idx] = cs;
+    sin_t[idx] = sn;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) rope_apply_kernel(T* __restrict__ x, const float* __restrict__ cos_t,
+                                                         const float* __restrict__ sin_t, int64_t ntok, int H,
+                                                         int Dh, int64_t row_stride, int inverse) {
+  const int half = Dh >> 1, gph = half >> 3;  // vec8 groups per half head
+  const int items = H * gph;
+  for (int64_t tok = blockIdx.x; tok < ntok; tok += gridDim.x) {
+    T* xr = x + tok * row_stride;
+    const float* ct = cos_t + tok * half;
+    const float* st = sin_t + tok * half;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+      const int h = it / gph, gi = it - h * gph;
+      float a[8], b[8], c[8], s[8];
+      Vec8<T>::load(xr + h * Dh + gi * 8, a);
+      Vec8<T>::load(xr + h * Dh + half + gi * 8, b);
+      load8f(ct + gi * 8, c);
+      load8f(st + gi * 8, s);
+      float oa[8], ob[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sn = inverse ? -s[e] : s[e];
+        oa[e] = a[e] * c[e] - b[e] * sn;
+        ob[e] = b[e] * c[e] + a[e] * sn;
+      }
+      Vec8<T>::store(xr + h * Dh + gi * 8, oa);
+      Vec8<T>::store(xr + h * Dh + half + gi * 8, ob);
+    }
+  }
+}
+
+int nch_for(int64_t D) {
+  const int64_t need = (D / 8 + 63) / 64;
+  if (need <= 2) return 2;
+  if (need <= 4) return 4;
+  if (need <= 8) return 8;
+  if (need <= 16) return 16;
+  return -1;
+}
+
+inline int row_grid(int64_t rows) {
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+#define DISPATCH_NCH(nch, ...)                \
+  switch (nch) {                              \
+    case 2: { constexpr int NCH = 2; __VA_ARGS__; break; }   \
+    case 4: { constexpr int NCH = 4; __VA_ARGS__; break; }   \
+    case 8: { constexpr int NCH = 8; __VA_ARGS__; break; }   \
+    case 16: { constexpr int NCH = 16; __VA_ARGS__; break; } \
+    default: return CMB_ERR_SHAPE;            \
+  }
+
+template <typename T>
+int ln_fwd(const void* x, int64_t rows, int64_t D, int64_t ldx, const float* add, int side, int grid_r,
+           const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd,
+           hipStream_t s) {
+  const int nch = nch_for(D);
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,
+                                       (const T*)x, rows, (int)D, ldx, add, side, grid_r, gamma, beta, eps,
+                                       (T*)y, ldy, mean, rstd));
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+template <typename T, typename TDx, bool ACCUM>
+int ln_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t rows, int64_t D, const float* add,
+           int side, int grid_r, const float* gamma, const float* mean, const float* rstd, void* dx,
+           int64_t lddx, float* dgamma, float* dbeta, float* dadd, hipStream_t s) {
+  const int nch = nch_for(D);
+  if (nch > 4) return CMB_ERR_SHAPE;  // register budget: the backward supports D <= 2048
+  const int npos = grid_r * grid_r;
+  const int64_t nwin = rows / npos;
+  int64_t blocks = (nwin + 63) / 64;  // ~16 rows per wave: amortises the end-of-block atomics
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  const size_t smem = (size_t)4 * D * sizeof(float);
+  if (nch == 2)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, TDx, 2, ACCUM>), dim3((unsigned)blocks, npos), dim3(256), smem, s,
+                       (const T*)dy, lddy, (const T*)x, ldx, rows, (int)D, add, side, grid_r, gamma, mean, rstd,
+                       (TDx*)dx, lddx, dgamma, dbeta, dadd);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, TDx, 4, ACCUM>), dim3((unsigned)blocks, npos), dim3(256), smem, s,
+                       (const T*)dy, lddy, (const T*)x, ldx, rows, (int)D, add, side, grid_r, gamma, mean, rstd,
+                       (TDx*)dx, lddx, dgamma, dbeta, dadd);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+}  // namespace
+
+extern "C" int cmb_layernorm_fwd(int dtype, const void* x, int64_t rows, int64_t D, int64_t ldx,
+                                 const float* add, int32_t side, int32_t grid_r, const float* gamma,
+                                 const float* beta, float eps, void* y, int64_t ldy, float* mean,
+                                 float* rstd, void* stream) {
+  if (!x || !y || rows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
+  if ((gamma == nullptr) != (beta == nullptr)) return CMB_ERR_BAD_ARG;
+  if (add && (side <= 0 || grid_r <= 0 || side % grid_r)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  if (!add) { side = 1; grid_r = 1; }
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CMB_BF16)
+    return ln_fwd<bf16_t>(x, rows, D, ldx, add, side, grid_r, gamma, beta, eps, y, ldy, mean, rstd, s);
+  if (dtype == CMB_F32)
+    return ln_fwd<float>(x, rows, D, ldx, add, side, grid_r, gamma, beta, eps, y, ldy, mean, rstd, s);
+  return CMB_ERR_BAD_ARG;
+}
+
+// dx dtype: same as `dtype` when dx_accumulate == 0; fp32 when dx_accumulate != 0 (the cross-layer
+// accumulator of the shared aux features is kept in fp32).
+extern "C" int cmb_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                                 int64_t rows, int64_t D, const float* add, int32_t side, int32_t grid_r,
+                                 const float* gamma, const float* mean, const float* rstd, void* dx,
+                                 int64_t lddx, int32_t dx_accumulate, float* dgamma, float* dbeta,
+                                 float* dadd, void* stream) {
+  if (!dy || !x || !dx || !mean || !rstd || rows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
+  if (add && (side <= 0 || grid_r <= 0 || side % grid_r)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  if (!add) { side = 1; grid_r = 1; }
+  if (add && rows % ((int64_t)side * side)) return CMB_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CMB_BF16) {
+    if (dx_accumulate)
+      return ln_bwd<bf16_t, float, true>(dy, lddy, x, ldx, rows, D, add, side, grid_r, gamma, mean, rstd, dx,
+                                         lddx, dgamma, dbeta, dadd, s);
+    return ln_bwd<bf16_t, bf16_t, false>(dy, lddy, x, ldx, rows, D, add, side, grid_r, gamma, mean, rstd, dx,
+                                         lddx, dgamma, dbeta, dadd, s);
+  }
+  if (dtype == CMB_F32) {
+    if (dx_accumulate)
+      return ln_bwd<float, float, true>(dy, lddy, x, ldx, rows, D, add, side, grid_r, gamma, mean, rstd, dx,
+                                        lddx, dgamma, dbeta, dadd, s);
+    return ln_bwd<float, float, false>(dy, lddy, x, ldx, rows, D, add, side, grid_r, gamma, mean, rstd, dx,
+                                       lddx, dgamma, dbeta, dadd, s);
+  }
+  return CMB_ERR_BAD_ARG;
+}
+
+extern "C" int cmb_rmsnorm_fwd(int dtype, const void* x, int64_t rows, int64_t D, const float* w, float eps,
+                               void* y, float* rstd, void* stream) {
+  if (!x || !y || !w || rows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = nch_for(D);
+  if (dtype == CMB_BF16) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((rmsnorm_fwd_kernel<bf16_t, NCH>), dim3(row_grid(rows)), dim3(256), 0,
+                                         s, (const bf16_t*)x, rows, (int)D, w, eps, (bf16_t*)y, rstd));
+  } else if (dtype == CMB_F32) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((rmsnorm_fwd_kernel<float, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,
+                                         (const float*)x, rows, (int)D, w, eps, (float*)y, rstd));
+  } else {
+    return CMB_ERR_BAD_ARG;
+  }
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+template <typename T>
+static int rms_bwd(const void* dy, const void* x, int64_t rows, int64_t D, const float* w, const float* rstd,
+                   void* dx, float* dw, hipStream_t s) {
+  const int nch = nch_for(D);
+  int64_t blocks = dw ? (rows + 63) / 64 : (rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  const size_t smem = dw ? (size_t)4 * D * sizeof(float) : 0;
+  if (dw) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, NCH, true>), dim3((unsigned)blocks), dim3(256),
+                                         smem, s, (const T*)dy, (const T*)x, rows, (int)D, w, rstd, (T*)dx, dw));
+  } else {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T, NCH, false>), dim3((unsigned)blocks), dim3(256),
+                                         smem, s, (const T*)dy, (const T*)x, rows, (int)D, w, rstd, (T*)dx, dw));
+  }
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_rmsnorm_bwd(int dtype, const void* dy, const void* x, int64_t rows, int64_t D,
+                               const float* w, const float* rstd, void* dx, float* dw, void* stream) {
+  if (!dy || !x || !w || !rstd || !dx || rows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CMB_BF16) return rms_bwd<bf16_t>(dy, x, rows, D, w, rstd, dx, dw, s);
+  if (dtype == CMB_F32) return rms_bwd<float>(dy, x, rows, D, w, rstd, dx, dw, s);
+  return CMB_ERR_BAD_ARG;
+}
+
+extern "C" int cmb_rope_table(const int64_t* position_ids, int64_t ntok, int64_t Dh, float base,
+                              float* cos_t, float* sin_t, void* stream) {
+  if (!position_ids || !cos_t || !sin_t || ntok < 0 || Dh <= 0 || (Dh & 1)) return CMB_ERR_BAD_ARG;
+  if (ntok == 0) return CMB_OK;
+  const int half = (int)(Dh / 2);
+  int64_t blocks = (ntok * half + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, position_ids,
+                     ntok, half, (int)Dh, base, cos_t, sin_t);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_rope_apply(int dtype, void* x, const float* cos_t, const float* sin_t, int64_t ntok,
+                              int64_t H, int64_t Dh, int64_t row_stride, int32_t inverse, void* stream) {
+  if (!x || !cos_t || !sin_t || ntok < 0 || H <= 0 || Dh <= 0 || (Dh & 15)) return CMB_ERR_BAD_ARG;
+  if (ntok == 0) return CMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t items = H * (Dh / 16);
+  int threads = items >= 256 ? 256 : (int)((items + 63) / 64 * 64);
+  int64_t blocks = ntok > 65535 ? 65535 : ntok;
+  if (dtype == CMB_BF16)
+    hipLaunchKernelGGL(rope_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(threads), 0, s, (bf16_t*)x, cos_t,
+                       sin_t, ntok, (int)H, (int)Dh, row_stride, inverse);
+  else if (dtype == CMB_F32)
+    hipLaunchKernelGGL(rope_apply_kernel<float>, dim3((unsigned)blocks), dim3(threads), 0, s, (float*)x, cos_t,
+                       sin_t, ntok, (int)H, (int)Dh, row_stride, inverse);
+  else
+    return CMB_ERR_BAD_ARG;
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}

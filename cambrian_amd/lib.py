@@ -1,0 +1,155 @@
+"""ctypes binding of ``libcambrian_amd.so`` (the C-ABI declared in ``include/cambrian_amd.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C cambrian_amd/csrc``.  There is
+deliberately NO fallback: if the shared object is missing, or a kernel returns a non-zero status, this
+module raises — a silent eager/PyTorch path would void every parity claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcambrian_amd.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
+ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf": ACT_GELU_ERF,
+             "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
+             "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
+SVA_MAX_TOWERS = 8
+
+STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
+          -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
+
+
+class CambrianAmdError(RuntimeError):
+    pass
+
+
+class RowMap(C.Structure):
+    _fields_ = [("n1", C.c_int64), ("n2", C.c_int64), ("s0", C.c_int64), ("s1", C.c_int64), ("s2", C.c_int64)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("A", C.c_void_p), ("a_map", RowMap),
+        ("B", C.c_void_p), ("ldb", C.c_int64),
+        ("C", C.c_void_p), ("c_map", RowMap),
+        ("bias", C.c_void_p), ("colscale", C.c_void_p),
+        ("residual", C.c_void_p), ("r_map", RowMap),
+        ("pre_out", C.c_void_p), ("p_map", RowMap),
+        ("act", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float),
+        ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+    ]
+
+
+class SvaDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("B", C.c_int32), ("qside", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32), ("ntowers", C.c_int32),
+        ("window_major", C.c_int32),
+        ("r", C.c_int32 * SVA_MAX_TOWERS),
+        ("q", C.c_void_p), ("ldq", C.c_int64),
+        ("kv", C.c_void_p * SVA_MAX_TOWERS), ("ldkv", C.c_int64 * SVA_MAX_TOWERS),
+        ("mask", C.c_void_p * SVA_MAX_TOWERS),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("lse", C.c_void_p),
+        ("dout", C.c_void_p), ("lddo", C.c_int64),
+        ("dq", C.c_void_p), ("lddq", C.c_int64),
+        ("dkv", C.c_void_p * SVA_MAX_TOWERS),
+    ]
+
+
+# symbol -> (restype, argtypes); every symbol of include/cambrian_amd.h must be listed here
+# (tests/test_abi.py cross-checks this table against the header).
+_i32, _i64, _f, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+SIGNATURES = {
+    "cmb_version": (C.c_char_p, []),
+    "cmb_abi_version": (C.c_int, []),
+    "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
+    "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
+    "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
+    "cmb_cast": (C.c_int, [C.c_int, _p, C.c_int, _p, _i64, _p]),
+    "cmb_layernorm_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _p, _i64, _p, _p, _p]),
+    "cmb_layernorm_bwd": (C.c_int, [C.c_int, _p, _i64, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _i64,
+                                    _i32, _p, _p, _p, _p]),
+    "cmb_rmsnorm_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _p, _f, _p, _p, _p]),
+    "cmb_rmsnorm_bwd": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "cmb_rope_table": (C.c_int, [_p, _i64, _i64, _f, _p, _p, _p]),
+    "cmb_rope_apply": (C.c_int, [C.c_int, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p]),
+    "cmb_sva_attn_fwd": (C.c_int, [C.POINTER(SvaDesc), _p]),
+    "cmb_sva_attn_bwd": (C.c_int, [C.POINTER(SvaDesc), _p]),
+    "cmb_embed_splice_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p]),
+    "cmb_embed_splice_bwd": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _i64, _i32, _p, _p, _p]),
+    "cmb_token_mean_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
+    "cmb_token_mean_bwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
+    "cmb_vit_attn_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i32, _i32, _f, _p, _i32, _p]),
+    "cmb_patchify_nchw": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _i32, C.c_int, _p, _i64, _p]),
+    "cmb_patchify2x2_nhwc": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "cmb_dwconv7x7_nhwc": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p]),
+    "cmb_resample_bilinear": (C.c_int, [C.c_int, _p, _i64, _i32, _i32, _i64, _i64, _i64, _p, _i32, _i32, _i64, _i64, _p]),
+    "cmb_act_mul": (C.c_int, [C.c_int, _i32, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p]),
+    "cmb_act_bwd": (C.c_int, [C.c_int, _i32, _p, _p, _i64, _p, _p]),
+    "cmb_bcast_rows": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared object (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CambrianAmdError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C cambrian_amd/csrc`.  There is no PyTorch fallback for the hot path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise CambrianAmdError(f"{what} failed with {STATUS.get(rc, rc)}")
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.bfloat16:
+        return BF16
+    if t == torch.float32:
+        return F32
+    raise CambrianAmdError(f"unsupported dtype {t} (bf16 and fp32 only)")
+
+
+def stream_ptr(device: Optional[torch.device] = None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CambrianAmdError("cambrian_amd kernels need tensors on a ROCm device; got a CPU tensor "
+                                   "(there is no CPU fallback on the product path)")
+
+
+def identity_map(ld: int) -> RowMap:
+    return RowMap(0, 1, 0, 0, ld)
+
+
+def make_map(n1: int, n2: int, s0: int, s1: int, s2: int) -> RowMap:
+    return RowMap(n1, n2, s0, s1, s2)

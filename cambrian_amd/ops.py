@@ -1,0 +1,640 @@
+"""Host-side operators over the C-ABI kernels.
+
+Two layers:
+  * ``k_*``  — thin, stateless launchers (no autograd): validate, fill the C structs, call the library.
+  * ``*Fn`` / functional wrappers — ``torch.autograd.Function`` objects that pair each forward kernel
+    with its backward kernels, so the reference's modules (cambrian/model/vision_sampler.py,
+    cambrian_arch.py) can be re-stated on top of them without touching torch's own math kernels.
+
+Compute dtype is the dtype of the activation tensor (bf16 for training, fp32 for the parity path);
+parameters stay fp32 masters and are cast per call (the cast is itself ``cmb_cast``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+from .lib import RowMap, GemmDesc, SvaDesc
+
+
+# ================================================================================================
+# raw launchers
+# ================================================================================================
+def _kstep(dtype: torch.dtype) -> int:
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def k_cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Contiguous cast fp32<->bf16 through cmb_cast (returns x itself if nothing to do)."""
+    if x.dtype == dtype and x.is_contiguous():
+        return x
+    L.require_gpu(x)
+    xc = x if x.is_contiguous() else x.contiguous()
+    if xc.dtype == dtype:
+        return xc
+    out = torch.empty(xc.shape, dtype=dtype, device=xc.device)
+    rc = L.load().cmb_cast(L.dtype_code(xc.dtype), xc.data_ptr(), L.dtype_code(dtype), out.data_ptr(), xc.numel(),
+                           L.stream_ptr(xc.device))
+    L.check(rc, "cmb_cast")
+    return out
+
+
+def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: Optional[RowMap] = None,
+           bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, colscale: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None, r_map: Optional[RowMap] = None,
+           out: Optional[torch.Tensor] = None, c_map: Optional[RowMap] = None, out_dtype: Optional[torch.dtype] = None,
+           pre_out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
+           split_k: int = 1) -> torch.Tensor:
+    """C[M,N] = epilogue(alpha * A[M,K] @ W[N,K]^T).  ``a`` is [M,K] (row stride a.stride(0)) unless an
+    explicit ``a_map``/``M`` is given, in which case ``a`` is just the base tensor."""
+    L.require_gpu(a, w, bias, colscale, residual, out, pre_out)
+    dt = a.dtype
+    if w.dtype != dt:
+        raise L.CambrianAmdError(f"gemm operand dtypes differ: {dt} vs {w.dtype}")
+    N, K = w.shape
+    if w.stride(1) != 1:
+        raise L.CambrianAmdError("gemm weight must be K-contiguous")
+    if a_map is None:
+        if a.dim() != 2 or a.stride(1) != 1 or a.shape[1] != K:
+            raise L.CambrianAmdError(f"gemm A must be [M,{K}] K-contiguous, got {tuple(a.shape)}")
+        M = a.shape[0]
+        a_map = L.identity_map(a.stride(0))
+    assert M is not None
+    odt = out_dtype or (out.dtype if out is not None else dt)
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+        c_map = L.identity_map(N)
+    elif c_map is None:
+        if out.dim() != 2 or out.stride(1) != 1:
+            raise L.CambrianAmdError("gemm out must be 2-D row-major unless c_map is given")
+        c_map = L.identity_map(out.stride(0))
+    d = GemmDesc()
+    d.dtype = L.dtype_code(dt)
+    d.out_dtype = L.dtype_code(out.dtype)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.a_map = a.data_ptr(), a_map
+    d.B, d.ldb = w.data_ptr(), w.stride(0)
+    d.C, d.c_map = out.data_ptr(), c_map
+    for t in (bias, colscale):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != N):
+            raise L.CambrianAmdError("bias / colscale must be contiguous fp32 [N]")
+    d.bias = L.ptr(bias)
+    d.colscale = L.ptr(colscale)
+    if residual is not None:
+        if residual.dtype != dt:
+            raise L.CambrianAmdError("residual dtype must equal the operand dtype")
+        if r_map is None:
+            if residual.dim() != 2 or residual.stride(1) != 1:
+                raise L.CambrianAmdError("residual must be 2-D row-major unless r_map is given")
+            r_map = L.identity_map(residual.stride(0))
+        d.residual, d.r_map = residual.data_ptr(), r_map
+    else:
+        d.residual, d.r_map = None, L.identity_map(0)
+    if pre_out is not None:
+        if pre_out.dtype != dt or not pre_out.is_contiguous():
+            raise L.CambrianAmdError("pre_out must be contiguous and of the operand dtype")
+        d.pre_out, d.p_map = pre_out.data_ptr(), L.identity_map(N)
+    else:
+        d.pre_out, d.p_map = None, L.identity_map(0)
+    d.act, d.alpha, d.beta = act, alpha, beta
+    d.split_k = split_k
+    ws = None
+    if split_k > 1:
+        ws = torch.empty((split_k * M * N,), dtype=torch.float32, device=a.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    else:
+        d.workspace, d.workspace_bytes = None, 0
+    rc = L.load().cmb_gemm(C.byref(d), L.stream_ptr(a.device))
+    L.check(rc, f"cmb_gemm(M={M},N={N},K={K},{dt})")
+    return out
+
+
+def k_transpose(x: torch.Tensor, r_pad: Optional[int] = None) -> torch.Tensor:
+    """[R,C] -> [C,R_pad] (zero padded)."""
+    L.require_gpu(x)
+    R, Cc = x.shape
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    r_pad = r_pad or pad_to(R, 8)
+    out = torch.empty((Cc, r_pad), dtype=x.dtype, device=x.device)
+    rc = L.load().cmb_transpose(L.dtype_code(x.dtype), x.data_ptr(), R, Cc, x.stride(0), out.data_ptr(), r_pad,
+                                L.stream_ptr(x.device))
+    L.check(rc, "cmb_transpose")
+    return out
+
+
+def k_colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    L.require_gpu(x)
+    R, Cc = x.shape
+    if out is None:
+        out = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+    rc = L.load().cmb_colsum(L.dtype_code(x.dtype), x.data_ptr(), R, Cc, x.stride(0), out.data_ptr(),
+                             L.stream_ptr(x.device))
+    L.check(rc, "cmb_colsum")
+    return out
+
+
+def k_token_mean(x3: torch.Tensor) -> torch.Tensor:
+    B, T, D = x3.shape
+    out = torch.empty((B, D), dtype=x3.dtype, device=x3.device)
+    rc = L.load().cmb_token_mean_fwd(L.dtype_code(x3.dtype), x3.data_ptr(), B, T, D, out.data_ptr(), L.stream_ptr(x3.device))
+    L.check(rc, "cmb_token_mean_fwd")
+    return out
+
+
+def k_segment_sum(x: torch.Tensor, rep: int) -> torch.Tensor:
+    """[M, D] -> [M/rep, D], summing each run of `rep` consecutive rows (the mean kernel, scaled by rep)."""
+    M, D = x.shape
+    xc = x if x.is_contiguous() else x.contiguous()
+    m = k_token_mean(xc.view(M // rep, rep, D))
+    return (m.to(torch.float32) * float(rep)).to(x.dtype)
+
+
+def k_layernorm_fwd(x, gamma, beta, eps, add=None, side=1, grid_r=1, want_stats=True):
+    L.require_gpu(x, gamma, beta, add)
+    rows, D = x.shape
+    y = torch.empty((rows, D), dtype=x.dtype, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_stats else None
+    rc = L.load().cmb_layernorm_fwd(L.dtype_code(x.dtype), x.data_ptr(), rows, D, x.stride(0), L.ptr(add), side, grid_r,
+                                    L.ptr(gamma), L.ptr(beta), eps, y.data_ptr(), D, L.ptr(mean), L.ptr(rstd),
+                                    L.stream_ptr(x.device))
+    L.check(rc, "cmb_layernorm_fwd")
+    return y, mean, rstd
+
+
+def k_layernorm_bwd(dy, x, mean, rstd, gamma=None, add=None, side=1, grid_r=1, dx_acc: Optional[torch.Tensor] = None,
+                    want_dgamma=True, want_dadd=True):
+    """Returns (dx, dgamma, dbeta, dadd).  With ``dx_acc`` (fp32 [rows,D]) dx is accumulated there and the
+    returned dx is None."""
+    L.require_gpu(dy, x, mean, rstd, gamma, add, dx_acc)
+    rows, D = x.shape
+    dev = x.device
+    if dy.stride(1) != 1:
+        dy = dy.contiguous()
+    dgamma = torch.zeros((D,), dtype=torch.float32, device=dev) if (gamma is not None and want_dgamma) else None
+    dbeta = torch.zeros((D,), dtype=torch.float32, device=dev) if (gamma is not None and want_dgamma) else None
+    dadd = torch.zeros_like(add) if (add is not None and want_dadd) else None
+    if dx_acc is not None:
+        dx, acc = dx_acc, 1
+    else:
+        dx, acc = torch.empty((rows, D), dtype=x.dtype, device=dev), 0
+    rc = L.load().cmb_layernorm_bwd(L.dtype_code(x.dtype), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), rows, D,
+                                    L.ptr(add), side, grid_r, L.ptr(gamma), mean.data_ptr(), rstd.data_ptr(),
+                                    dx.data_ptr(), D, acc, L.ptr(dgamma), L.ptr(dbeta), L.ptr(dadd),
+                                    L.stream_ptr(dev))
+    L.check(rc, "cmb_layernorm_bwd")
+    return (None if dx_acc is not None else dx), dgamma, dbeta, dadd
+
+
+def _fill_sva(desc: SvaDesc, q, kvs, masks, r_list, B, qside, heads, hd, window_major=False):
+    desc.dtype = L.dtype_code(q.dtype)
+    desc.window_major = 1 if window_major else 0
+    desc.B, desc.qside, desc.heads, desc.hd, desc.ntowers = B, qside, heads, hd, len(kvs)
+    desc.q, desc.ldq = q.data_ptr(), q.stride(0)
+    for i, (kv, r) in enumerate(zip(kvs, r_list)):
+        G = qside * r
+        if kv.dtype != q.dtype or tuple(kv.shape) != (B * G * G, 2 * heads * hd) or kv.stride(1) != 1:
+            raise L.CambrianAmdError(f"kv[{i}] must be [{B * G * G},{2 * heads * hd}] of {q.dtype}, got {tuple(kv.shape)}")
+        desc.r[i] = r
+        desc.kv[i], desc.ldkv[i] = kv.data_ptr(), kv.stride(0)
+        m = masks[i] if masks is not None else None
+        if m is not None:
+            if m.dtype != torch.uint8 or not m.is_contiguous() or m.numel() != B * qside * qside * r * r:
+                raise L.CambrianAmdError(f"mask[{i}] must be contiguous uint8 [{B * qside * qside},{r * r}]")
+            desc.mask[i] = m.data_ptr()
+        else:
+            desc.mask[i] = None
+
+
+def k_sva_attn_fwd(q, kvs, masks, r_list, B, qside, heads, hd, window_major=False):
+    L.require_gpu(q, *kvs)
+    d = SvaDesc()
+    _fill_sva(d, q, kvs, masks, r_list, B, qside, heads, hd, window_major)
+    Bq = B * qside * qside
+    out = torch.empty((Bq, heads * hd), dtype=q.dtype, device=q.device)
+    lse = torch.empty((Bq, heads), dtype=torch.float32, device=q.device)
+    d.out, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
+    rc = L.load().cmb_sva_attn_fwd(C.byref(d), L.stream_ptr(q.device))
+    L.check(rc, "cmb_sva_attn_fwd")
+    return out, lse
+
+
+def k_sva_attn_bwd(dout, q, kvs, masks, r_list, out, lse, B, qside, heads, hd, window_major=False):
+    d = SvaDesc()
+    _fill_sva(d, q, kvs, masks, r_list, B, qside, heads, hd, window_major)
+    if dout.stride(1) != 1:
+        dout = dout.contiguous()
+    dq = torch.empty_like(q)
+    dkvs = [torch.empty_like(kv) for kv in kvs]
+    d.out, d.ldo, d.lse = out.data_ptr(), out.stride(0), lse.data_ptr()
+    d.dout, d.lddo = dout.data_ptr(), dout.stride(0)
+    d.dq, d.lddq = dq.data_ptr(), dq.stride(0)
+    for i, t in enumerate(dkvs):
+        d.dkv[i] = t.data_ptr()
+    rc = L.load().cmb_sva_attn_bwd(C.byref(d), L.stream_ptr(q.device))
+    L.check(rc, "cmb_sva_attn_bwd")
+    return dq, dkvs
+
+
+# ================================================================================================
+# autograd: linear
+# ================================================================================================
+def _wgrad_splits(n_out: int, k_in: int, m_pad: int, kstep: int) -> int:
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    want = max(1, 768 // tiles)
+    return max(1, min(want, m_pad // kstep // 4, 64))
+
+
+def _as_dtype_contig(t: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    if t.dtype == dt and t.is_contiguous():
+        return t
+    return k_cast(t.contiguous(), dt)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) (* colscale) (+ residual).  x: [M,K] compute dtype; W: [N,K] fp32 master (or
+    compute dtype); gradients for W / b come out in fp32 straight from the fp32 accumulators.
+    ``res_rep`` > 0 means residual is [M/res_rep, N] and output row r adds residual[r // res_rep]
+    (the per-image context term of proj_in, vision_sampler.py:279-292, never materialised per query)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: int, residual, res_rep: int, colscale):
+        dt = x.dtype
+        w_c = k_cast(weight, dt)
+        b_c = None if bias is None else k_cast(bias, torch.float32)
+        need_pre = act != L.ACT_NONE and (x.requires_grad or weight.requires_grad
+                                          or (bias is not None and bias.requires_grad))
+        pre = torch.empty((x.shape[0], weight.shape[0]), dtype=dt, device=x.device) if need_pre else None
+        r_map = None
+        if residual is not None:
+            residual = _as_dtype_contig(residual, dt)
+            if res_rep > 0:
+                if residual.dim() != 2 or residual.shape[0] * res_rep != x.shape[0]:
+                    raise L.CambrianAmdError("broadcast residual must be [M/res_rep, N]")
+                r_map = L.make_map(res_rep, 1, residual.stride(0), 0, 0)
+        y = k_gemm(x, w_c, bias=b_c, act=act, residual=residual, r_map=r_map, colscale=colscale, pre_out=pre)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.res_rep = res_rep
+        ctx.save_for_backward(x, w_c, pre, colscale)
+        ctx.w_dtype = weight.dtype
+        ctx.b_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_c, pre, colscale = ctx.saved_tensors
+        dt = x.dtype
+        dy = _as_dtype_contig(dy, dt)
+        need_x, need_w, need_b, _, need_res, _, _ = ctx.needs_input_grad
+        M, K = x.shape
+        N = w_c.shape[0]
+        dres = None
+        if need_res:
+            dres = k_segment_sum(dy, ctx.res_rep) if ctx.res_rep > 0 else dy
+        g = dy
+        if colscale is not None:
+            g = dy * colscale.to(dt)  # LayerScale belongs to the frozen towers; kept for completeness
+        if ctx.act != L.ACT_NONE:
+            gp = torch.empty_like(pre)
+            rc = L.load().cmb_act_bwd(L.dtype_code(dt), ctx.act, g.data_ptr(), pre.data_ptr(), pre.numel(), gp.data_ptr(),
+                                      L.stream_ptr(g.device))
+            L.check(rc, "cmb_act_bwd")
+            g = gp
+        dx = dw = db = None
+        ks = _kstep(dt)
+        if need_x:
+            n_pad = pad_to(N, ks)
+            w_t = k_transpose(w_c, n_pad)  # [K, N_pad]
+            if n_pad != N:
+                gpad = torch.zeros((M, n_pad), dtype=dt, device=g.device)
+                gpad[:, :N] = g
+                dx = k_gemm(gpad, w_t)
+            else:
+                dx = k_gemm(g, w_t)
+        if need_w:
+            m_pad = pad_to(M, ks)
+            g_t = k_transpose(g, m_pad)  # [N, M_pad]
+            x_t = k_transpose(x, m_pad)  # [K, M_pad]
+            dw = k_gemm(g_t, x_t, out_dtype=torch.float32, split_k=_wgrad_splits(N, K, m_pad, ks))
+            if ctx.w_dtype != torch.float32:
+                dw = dw.to(ctx.w_dtype)
+        if need_b and ctx.has_bias:
+            db = k_colsum(g)
+            if ctx.b_dtype != torch.float32:
+                db = db.to(ctx.b_dtype)
+        return dx, dw, db, None, dres, None, None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE,
+           residual: Optional[torch.Tensor] = None, res_rep: int = 0,
+           colscale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """2-D linear on the HIP GEMM.  x [M,K] -> [M,N]."""
+    return LinearFn.apply(x, weight, bias, act, residual, res_rep, colscale)
+
+
+# ================================================================================================
+# autograd: LayerNorm (affine) and the SVA "normalise-only, shared input" variant
+# ================================================================================================
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        g32 = k_cast(gamma, torch.float32)
+        b32 = k_cast(beta, torch.float32)
+        y, mean, rstd = k_layernorm_fwd(x, g32, b32, eps)
+        ctx.save_for_backward(x, g32, mean, rstd)
+        ctx.p_dtype = gamma.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32, mean, rstd = ctx.saved_tensors
+        dy = _as_dtype_contig(dy, x.dtype)
+        dx, dgamma, dbeta, _ = k_layernorm_bwd(dy, x, mean, rstd, gamma=g32)
+        if ctx.p_dtype != torch.float32:
+            dgamma, dbeta = dgamma.to(ctx.p_dtype), dbeta.to(ctx.p_dtype)
+        return dx, dgamma, dbeta, None
+
+
+def layernorm(x, gamma, beta, eps: float = 1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class GradAccumulator:
+    """fp32 side buffer that the 13 SVA layers' LayerNorm backwards accumulate into (all layers read the
+    same aux feature tensor; SURVEY.md §7 "hard parts")."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.shape = None
+
+    def get(self, rows: int, D: int, device) -> torch.Tensor:
+        if self.buf is None:
+            self.buf = torch.zeros((rows, D), dtype=torch.float32, device=device)
+        return self.buf
+
+
+class SharedGradFn(torch.autograd.Function):
+    """Identity whose backward hands out the accumulator filled by the consumers (which themselves return
+    no gradient for this tensor).  Autograd runs this node only after every consumer node has run, because
+    dependencies are counted on graph edges, not on defined gradients."""
+
+    @staticmethod
+    def forward(ctx, x, holder: GradAccumulator):
+        ctx.holder = holder
+        holder.shape = x.shape
+        ctx.x_dtype = x.dtype
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf = ctx.holder.buf
+        ctx.holder.buf = None
+        if buf is None:
+            return g, None
+        if g is not None:
+            buf = buf + g.to(torch.float32).reshape(buf.shape)
+        return k_cast(buf, ctx.x_dtype).view(ctx.holder.shape), None
+
+
+def shared_grad(x: torch.Tensor, holder: GradAccumulator) -> torch.Tensor:
+    return SharedGradFn.apply(x, holder)
+
+
+class SvaNormFn(torch.autograd.Function):
+    """n = (x + pos[window_pos]) normalised without affine (the K- and V-LayerNorm affines of
+    vision_sampler.py:173-174 are folded into the projection weights).  The gradient w.r.t. x goes into
+    the shared fp32 accumulator instead of being returned."""
+
+    @staticmethod
+    def forward(ctx, x, pos, holder: GradAccumulator, side: int, grid_r: int, eps: float):
+        add = None if pos is None else k_cast(pos, torch.float32)
+        n, mean, rstd = k_layernorm_fwd(x, None, None, eps, add=add, side=side, grid_r=grid_r)
+        ctx.holder, ctx.side, ctx.grid_r = holder, side, grid_r
+        ctx.pos_dtype = None if pos is None else pos.dtype
+        ctx.has_pos = pos is not None
+        if pos is None:
+            ctx.save_for_backward(x, mean, rstd)
+        else:
+            ctx.save_for_backward(x, mean, rstd, add)
+        return n
+
+    @staticmethod
+    def backward(ctx, dn):
+        if ctx.has_pos:
+            x, mean, rstd, add = ctx.saved_tensors
+        else:
+            (x, mean, rstd), add = ctx.saved_tensors, None
+        dn = _as_dtype_contig(dn, x.dtype)
+        need_x, need_pos = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dpos = None
+        if need_x:
+            acc = ctx.holder.get(x.shape[0], x.shape[1], x.device)
+            _, _, _, dpos = k_layernorm_bwd(dn, x, mean, rstd, add=add, side=ctx.side, grid_r=ctx.grid_r, dx_acc=acc,
+                                            want_dadd=need_pos)
+        elif need_pos and add is not None:
+            _, _, _, dpos = k_layernorm_bwd(dn, x, mean, rstd, add=add, side=ctx.side, grid_r=ctx.grid_r)
+        if dpos is not None and ctx.pos_dtype != torch.float32:
+            dpos = dpos.to(ctx.pos_dtype)
+        return None, dpos, None, None, None, None
+
+
+def sva_norm(x, pos, holder, side, grid_r, eps=1e-5):
+    return SvaNormFn.apply(x, pos, holder, side, grid_r, eps)
+
+
+# ================================================================================================
+# autograd: SVA attention core
+# ================================================================================================
+class SvaAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, B: int, qside: int, heads: int, hd: int, r_list, masks, window_major: bool, *kvs):
+        out, lse = k_sva_attn_fwd(q, list(kvs), masks, r_list, B, qside, heads, hd, window_major)
+        ctx.cfg = (B, qside, heads, hd, tuple(r_list), window_major)
+        ctx.masks = masks
+        ctx.save_for_backward(q, out, lse, *kvs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, out, lse, *kvs = ctx.saved_tensors
+        B, qside, heads, hd, r_list, window_major = ctx.cfg
+        dout = _as_dtype_contig(dout, q.dtype)
+        dq, dkvs = k_sva_attn_bwd(dout, q, kvs, ctx.masks, list(r_list), out, lse, B, qside, heads, hd, window_major)
+        return (dq, None, None, None, None, None, None, None, *dkvs)
+
+
+def sva_attention(q, kvs: Sequence[torch.Tensor], masks, r_list, B, qside, heads=16, hd=64, window_major=False):
+    return SvaAttnFn.apply(q, B, qside, heads, hd, list(r_list), masks, window_major, *kvs)
+
+
+# ================================================================================================
+# autograd: token mean, embedding splice
+# ================================================================================================
+class TokenMeanFn(torch.autograd.Function):
+    """[B,T,D] -> [B,D] mean over tokens (cambrian_arch.py:377).  If ``holder`` is given the gradient is
+    accumulated into the shared fp32 buffer of the aux feature instead of being returned."""
+
+    @staticmethod
+    def forward(ctx, x, holder: Optional[GradAccumulator]):
+        B, T, D = x.shape
+        xc = x if x.is_contiguous() else x.contiguous()
+        out = k_token_mean(xc)
+        ctx.shape = (B, T, D)
+        ctx.holder = holder
+        ctx.x_dtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, T, D = ctx.shape
+        g = _as_dtype_contig(g, ctx.x_dtype)
+        if ctx.holder is not None:
+            acc = ctx.holder.get(B * T, D, g.device)
+        else:
+            acc = torch.zeros((B * T, D), dtype=torch.float32, device=g.device)
+        rc = L.load().cmb_token_mean_bwd(L.dtype_code(g.dtype), g.data_ptr(), B, T, D, acc.data_ptr(), L.stream_ptr(g.device))
+        L.check(rc, "cmb_token_mean_bwd")
+        if ctx.holder is not None:
+            return None, None
+        return k_cast(acc, ctx.x_dtype).view(B, T, D), None
+
+
+def token_mean(x, holder=None):
+    return TokenMeanFn.apply(x, holder)
+
+
+class EmbedSpliceFn(torch.autograd.Function):
+    """inputs_embeds of the static path: embedding gather + newline column + visual splice in one kernel
+    (cambrian_arch.py:413-420,457-490).  Gradients flow to feat and newline; the embedding table is frozen
+    in the pre-training stage (train_fsdp.py:1677-1685)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, feat, newline, side: int, image_token: int):
+        B, S = ids.shape
+        V, H = table.shape
+        dt = feat.dtype
+        tab = k_cast(table, dt)
+        nl = k_cast(newline, dt)
+        featc = feat if feat.is_contiguous() else feat.contiguous()
+        out = torch.empty((B, S, H), dtype=dt, device=feat.device)
+        pos = torch.empty((B,), dtype=torch.int32, device=feat.device)
+        idc = ids if ids.is_contiguous() else ids.contiguous()
+        rc = L.load().cmb_embed_splice_fwd(L.dtype_code(dt), idc.data_ptr(), B, S, H, image_token, tab.data_ptr(), V,
+                                           featc.data_ptr(), side, nl.data_ptr(), out.data_ptr(), pos.data_ptr(),
+                                           L.stream_ptr(feat.device))
+        L.check(rc, "cmb_embed_splice_fwd")
+        ctx.cfg = (B, S, H, side, dt, newline.dtype)
+        ctx.save_for_backward(pos)
+        ctx.mark_non_differentiable(pos)
+        return out, pos
+
+    @staticmethod
+    def backward(ctx, dout, _dpos):
+        (pos,) = ctx.saved_tensors
+        B, S, H, side, dt, nl_dtype = ctx.cfg
+        if ctx.needs_input_grad[1]:
+            raise L.CambrianAmdError("training the embedding table through EmbedSpliceFn is not implemented "
+                                     "(the pre-training stage freezes it: train_fsdp.py:1677-1685)")
+        dout = _as_dtype_contig(dout, dt)
+        dfeat = torch.empty((B, side * side, H), dtype=dt, device=dout.device)
+        dnl = torch.zeros((H,), dtype=torch.float32, device=dout.device)
+        rc = L.load().cmb_embed_splice_bwd(L.dtype_code(dt), dout.data_ptr(), pos.data_ptr(), B, S, H, side,
+                                           dfeat.data_ptr(), dnl.data_ptr(), L.stream_ptr(dout.device))
+        L.check(rc, "cmb_embed_splice_bwd")
+        return None, None, dfeat, dnl.to(nl_dtype), None, None
+
+
+def embed_splice(ids, table, feat, newline, side: int, image_token: int = -200):
+    return EmbedSpliceFn.apply(ids, table, feat, newline, side, image_token)
+
+
+# ================================================================================================
+# autograd: RMSNorm / RoPE (LLM side)
+# ================================================================================================
+class RmsNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, eps: float):
+        shape = x.shape
+        D = shape[-1]
+        x2 = x.reshape(-1, D)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        w32 = k_cast(weight, torch.float32)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rc = L.load().cmb_rmsnorm_fwd(L.dtype_code(x.dtype), x2.data_ptr(), rows, D, w32.data_ptr(), eps, y.data_ptr(),
+                                      rstd.data_ptr(), L.stream_ptr(x.device))
+        L.check(rc, "cmb_rmsnorm_fwd")
+        ctx.save_for_backward(x2, w32, rstd)
+        ctx.shape, ctx.w_dtype = shape, weight.dtype
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w32, rstd = ctx.saved_tensors
+        rows, D = x2.shape
+        dy2 = _as_dtype_contig(dy.reshape(rows, D), x2.dtype)
+        dx = torch.empty_like(x2)
+        dw = torch.zeros((D,), dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[1] else None
+        rc = L.load().cmb_rmsnorm_bwd(L.dtype_code(x2.dtype), dy2.data_ptr(), x2.data_ptr(), rows, D, w32.data_ptr(),
+                                      rstd.data_ptr(), dx.data_ptr(), L.ptr(dw), L.stream_ptr(x2.device))
+        L.check(rc, "cmb_rmsnorm_bwd")
+        if dw is not None and ctx.w_dtype != torch.float32:
+            dw = dw.to(ctx.w_dtype)
+        return dx.view(ctx.shape), dw, None
+
+
+def rmsnorm(x, weight, eps: float = 1e-6):
+    return RmsNormFn.apply(x, weight, eps)
+
+
+def rope_table(position_ids: torch.Tensor, head_dim: int, base: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [ntok, head_dim/2] fp32 for position_ids [B,S] (built once per forward)."""
+    L.require_gpu(position_ids)
+    pid = position_ids.reshape(-1).to(torch.int64).contiguous()
+    ntok = pid.numel()
+    cos = torch.empty((ntok, head_dim // 2), dtype=torch.float32, device=pid.device)
+    sin = torch.empty_like(cos)
+    rc = L.load().cmb_rope_table(pid.data_ptr(), ntok, head_dim, base, cos.data_ptr(), sin.data_ptr(),
+                                 L.stream_ptr(pid.device))
+    L.check(rc, "cmb_rope_table")
+    return cos, sin
+
+
+class RopeFn(torch.autograd.Function):
+    """x [ntok, H, Dh] (contiguous) rotated out of place; the backward is the inverse rotation."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        y = x.contiguous().clone()
+        ntok, H, Dh = y.shape
+        rc = L.load().cmb_rope_apply(L.dtype_code(y.dtype), y.data_ptr(), cos.data_ptr(), sin.data_ptr(), ntok, H, Dh,
+                                     H * Dh, 0, L.stream_ptr(y.device))
+        L.check(rc, "cmb_rope_apply")
+        ctx.save_for_backward(cos, sin)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cos, sin = ctx.saved_tensors
+        g = dy.contiguous().clone()
+        ntok, H, Dh = g.shape
+        rc = L.load().cmb_rope_apply(L.dtype_code(g.dtype), g.data_ptr(), cos.data_ptr(), sin.data_ptr(), ntok, H, Dh,
+                                     H * Dh, 1, L.stream_ptr(g.device))
+        L.check(rc, "cmb_rope_apply(inverse)")
+        return g, None, None
+
+
+def rope(x, cos, sin):
+    return RopeFn.apply(x, cos, sin)

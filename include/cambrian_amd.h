@@ -1,0 +1,249 @@
+/*
+ * cambrian_amd.h — C-ABI of the MI355X (gfx950) kernel library behind Cambrian-1's
+ * vision-tower + Spatial-Vision-Aggregator (SVA) hot path.
+ *
+ * The reference (cambrian-mllm/cambrian) is 100 % Python and has no FFI of its own
+ * (SURVEY.md §8b); every entry point below therefore cites the *library call site* in the
+ * reference that it replaces (file:line relative to the reference repo root).  The Python
+ * host side (cambrian_amd/ops.py) binds these symbols with ctypes and wraps them in
+ * torch.autograd.Function objects; INTEGRATION.md shows the binding a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, scalars, POD structs.  No torch / C++ types.
+ *   - every buffer is caller-owned device memory (HBM) valid on the given stream.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ *   - every function returns 0 (CMB_OK) or a negative cmb_status; nothing throws, nothing
+ *     synchronises the host, nothing allocates.
+ *   - dtype codes: CMB_BF16 = 0 (bf16 storage, fp32 accumulate), CMB_F32 = 1 (exact fp32
+ *     path on v_mfma_f32_32x32x2_f32; used by the parity tests).
+ *   - "rowmap": a logical row index r of a [rows, cols] matrix is mapped to an element
+ *     offset  (r / n1) * s0 + ((r % n1) / n2) * s1 + (r % n2) * s2 ; n1 == 0 means the
+ *     plain row-major case r * s2.  This is how the window re-arrangement
+ *     (cambrian_arch.py:271-287) and the in-LLM slice hidden[:, 91:691] viewed as
+ *     [B,24,25,H][:, :, :24] (cambrian_llama.py:181-207) are folded into the consumer's
+ *     loads instead of being materialised.
+ */
+#ifndef CAMBRIAN_AMD_H
+#define CAMBRIAN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cmb_status {
+  CMB_OK = 0,
+  CMB_ERR_BAD_ARG = -1,      /* null pointer, negative size, unsupported combination */
+  CMB_ERR_ALIGNMENT = -2,    /* pointer / leading dimension not 16-byte aligned */
+  CMB_ERR_SHAPE = -3,        /* K not a multiple of the K-step, N not a multiple of 8, ... */
+  CMB_ERR_WORKSPACE = -4,    /* workspace too small */
+  CMB_ERR_LAUNCH = -5        /* hipLaunchKernel / hipFuncSetAttribute failed */
+} cmb_status;
+
+enum { CMB_BF16 = 0, CMB_F32 = 1 };
+enum { CMB_ACT_NONE = 0, CMB_ACT_GELU_ERF = 1, CMB_ACT_GELU_TANH = 2, CMB_ACT_QUICK_GELU = 3,
+       CMB_ACT_SILU = 4 };
+
+typedef struct cmb_rowmap {
+  int64_t n1, n2;      /* n1 == 0: identity (offset = r * s2) */
+  int64_t s0, s1, s2;  /* element strides */
+} cmb_rowmap;
+
+/* library / build identification ("cambrian_amd <version> gfx950"). */
+const char* cmb_version(void);
+/* number of tensor-core tile configurations compiled in (diagnostic). */
+int cmb_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM   C[M,N] = epilogue( alpha * A[M,K] · B[N,K]^T )            (nn.Linear layout)
+ * replaces: every torch.nn.Linear / F.linear on the path —
+ *   vision_sampler.py:170-175,187-189,232,240-245,254-255 (SVA projections),
+ *   cambrian_arch.py:49,56,375,411 (mm_projector_aux_i / mm_projector),
+ *   HF CLIPVisionModel / Dinov2Model / timm ViT + ConvNeXt linears reached from
+ *   clip_encoder.py:104, siglip_encoder.py:97, dino_encoder.py:159, clip_convnext_encoder.py:133-136.
+ * epilogue order:  v = alpha*acc + bias[n];  pre_out = v;  v = act(v);  v *= colscale[n];
+ *                  v += residual[m,n];  v += beta*C_old[m,n] (fp32 C only);  C = v
+ * requirements: K % (128 / sizeof(elem)) == 0; N % 8 == 0; 16-byte aligned rows.
+ * split_k > 1: fp32 partial slabs go to `workspace` (split_k*M*N*4 bytes) and are reduced by a
+ *   second kernel; only alpha/beta and out_dtype apply (used for weight gradients).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cmb_gemm_desc {
+  int32_t dtype;       /* CMB_BF16 | CMB_F32 : element type of A, B, residual, pre_out */
+  int32_t out_dtype;   /* CMB_BF16 | CMB_F32 : element type of C (bf16 requires dtype bf16) */
+  int64_t M, N, K;
+  const void* A;  cmb_rowmap a_map;
+  const void* B;  int64_t ldb;
+  void* C;        cmb_rowmap c_map;
+  const float* bias;       /* [N] fp32 or NULL */
+  const float* colscale;   /* [N] fp32 or NULL (LayerScale) */
+  const void* residual; cmb_rowmap r_map;  /* NULL or [M,N] of `dtype` */
+  void* pre_out;        cmb_rowmap p_map;  /* NULL or [M,N] of `dtype`: pre-activation copy */
+  int32_t act;
+  float alpha, beta;
+  int32_t split_k;
+  void* workspace; int64_t workspace_bytes;
+} cmb_gemm_desc;
+
+int cmb_gemm(const cmb_gemm_desc* d, void* stream);
+
+/* out[C, R_pad] = in[R, C]^T, zero-filling columns R..R_pad-1 (R_pad >= R). Used to put the
+ * reduction dimension innermost for weight-gradient GEMMs (autograd of the linears above). */
+int cmb_transpose(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in,
+                  void* out, int64_t R_pad, void* stream);
+
+/* out[c] (fp32) += sum_r in[r, c]   — bias gradients (atomic accumulate; caller zero-fills). */
+int cmb_colsum(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in,
+               float* out, void* stream);
+
+/* y = (T)x elementwise casts between fp32 and bf16 (n elements). to_dtype/from_dtype are CMB_*. */
+int cmb_cast(int from_dtype, const void* in, int to_dtype, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm   y[r,:] = (x[r,:] (+ add[pos(r),:]) - mean) * rstd (* gamma + beta)
+ * replaces: nn.LayerNorm at vision_sampler.py:170,173-174,261 and cambrian_arch.py:56, the
+ *   pos_embed add at vision_sampler.py:304-309, and the HF/timm LayerNorms of the towers.
+ * add: optional [grid_r*grid_r, D] fp32 table (SVA pos_embed_i); the row -> table-row map is
+ *   the window-local position of token r on a square side×side token grid:
+ *   pos = ((r % (side*side)) / side % grid_r) * grid_r + (r % side) % grid_r.
+ * gamma/beta may be NULL (pure normalisation: the SVA path folds the K- and V-LayerNorm affines
+ *   into the projection weights so that one normalised tensor serves both).
+ * mean/rstd: optional fp32 [rows] outputs for the backward.
+ * ---------------------------------------------------------------------------------------- */
+int cmb_layernorm_fwd(int dtype, const void* x, int64_t rows, int64_t D, int64_t ldx,
+                      const float* add, int32_t side, int32_t grid_r,
+                      const float* gamma, const float* beta, float eps,
+                      void* y, int64_t ldy, float* mean, float* rstd, void* stream);
+
+/* dx (+)= LN backward.  dy: [rows,D]; xhat is recomputed from x (+add), mean, rstd.
+ * dx_accumulate != 0: dx += result (gradient accumulation across the 13 SVA layers that share
+ * the aux features, SURVEY.md §7 "hard parts").  dgamma/dbeta/dadd are fp32 and are
+ * *accumulated into* (atomics), caller zero-fills; any may be NULL. */
+int cmb_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                      int64_t rows, int64_t D,
+                      const float* add, int32_t side, int32_t grid_r,
+                      const float* gamma, const float* mean, const float* rstd,
+                      void* dx, int64_t lddx, int32_t dx_accumulate,
+                      float* dgamma, float* dbeta, float* dadd, void* stream);
+
+/* RMSNorm: y = (x * rsqrt(mean(x^2)+eps)) * w, fp32 math, weight multiplied BEFORE the down-cast
+ * (the reference's patched LlamaRMSNorm: train_fsdp.py:1429-1438; phi3/modeling_phi3.py:83-97). */
+int cmb_rmsnorm_fwd(int dtype, const void* x, int64_t rows, int64_t D, const float* w, float eps,
+                    void* y, float* rstd, void* stream);
+int cmb_rmsnorm_bwd(int dtype, const void* dy, const void* x, int64_t rows, int64_t D,
+                    const float* w, const float* rstd, void* dx, float* dw, void* stream);
+
+/* RoPE (rotate-half form): x[t,h,:] = x*cos + rotate_half(x)*sin with
+ * cos/sin = cos/sin(position_ids[t] * base^(-2i/Dh)) evaluated in fp32
+ * (phi3/modeling_phi3.py:114-141,257-281 and the HF Llama equivalent).
+ * cmb_rope_table builds the [ntok, Dh/2] fp32 tables once per forward; cmb_rope_apply rotates
+ * x [ntok, H, Dh] (token stride row_stride elements) in place; inverse != 0 applies the transposed
+ * rotation (the backward). */
+int cmb_rope_table(const int64_t* position_ids, int64_t ntok, int64_t Dh, float base,
+                   float* cos_t, float* sin_t, void* stream);
+int cmb_rope_apply(int dtype, void* x, const float* cos_t, const float* sin_t, int64_t ntok,
+                   int64_t H, int64_t Dh, int64_t row_stride, int32_t inverse, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SVA windowed cross-attention core  (vision_sampler.py:193-230, F.scaled_dot_product_attention
+ * at :215-220, with the window partition of cambrian_arch.py:271-287 done by index arithmetic).
+ *   q   : [Bq, heads*hd]            Bq = B * qside*qside queries, one query row each
+ *   kv_i: [B * (qside*r_i)^2, 2*heads*hd]  tower-token-major (NOT window-rearranged);
+ *         K = columns [0, heads*hd), V = columns [heads*hd, 2*heads*hd)
+ *   mask_i: uint8 [Bq, r_i*r_i] (1 = may attend), may be NULL (= all ones)
+ *   out : [Bq, heads*hd];  lse: fp32 [Bq, heads] (log-sum-exp of the scaled scores)
+ * query (b, qy, qx) attends, for every tower i, to tokens ((qy*r_i+ry)*qside*r_i + qx*r_i+rx).
+ * Softmax in fp32 over the concatenation of all towers' keys, scale = 1/sqrt(hd).
+ * ---------------------------------------------------------------------------------------- */
+#define CMB_SVA_MAX_TOWERS 8
+typedef struct cmb_sva_desc {
+  int32_t dtype;
+  int32_t B, qside, heads, hd, ntowers;
+  int32_t window_major;  /* 0: kv_i tower-token-major (below); 1: kv_i is [Bq, r_i*r_i, 2*heads*hd] */
+  int32_t r[CMB_SVA_MAX_TOWERS];
+  const void* q;   int64_t ldq;
+  const void* kv[CMB_SVA_MAX_TOWERS]; int64_t ldkv[CMB_SVA_MAX_TOWERS];
+  const uint8_t* mask[CMB_SVA_MAX_TOWERS];
+  void* out;       int64_t ldo;
+  float* lse;
+  /* backward only */
+  const void* dout; int64_t lddo;
+  void* dq;         int64_t lddq;
+  void* dkv[CMB_SVA_MAX_TOWERS];   /* same layout as kv; every element written exactly once */
+} cmb_sva_desc;
+
+int cmb_sva_attn_fwd(const cmb_sva_desc* d, void* stream);
+int cmb_sva_attn_bwd(const cmb_sva_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding merge (static layout): cambrian_arch.py:413-420 (newline column) + :457-490.
+ *   out[b,t,:] = feat[b, i*side+j, :]   if t = p_b + i*(side+1) + j, j < side
+ *              = newline[:]             if t = p_b + i*(side+1) + side
+ *              = table[ids'[b,t], :]    otherwise (ids' = ids with image_token -> 0)
+ * p_b = first index with ids[b,t] == image_token (rows without one are pure text).
+ * Copies only: bit-exact.  `pos` (int32 [B]) receives p_b (or -1).
+ * ---------------------------------------------------------------------------------------- */
+int cmb_embed_splice_fwd(int dtype, const int64_t* ids, int64_t B, int64_t S, int64_t H,
+                         int64_t image_token, const void* table, int64_t vocab,
+                         const void* feat, int32_t side, const void* newline,
+                         void* out, int32_t* pos, void* stream);
+/* dfeat[b,i*side+j,:] = dout[b, p_b+i*(side+1)+j, :];  dnewline (fp32 [H], accumulated) +=
+ * sum_{b,i} dout[b, p_b+i*(side+1)+side, :]. */
+int cmb_embed_splice_bwd(int dtype, const void* dout, const int32_t* pos, int64_t B, int64_t S,
+                         int64_t H, int32_t side, void* dfeat, float* dnewline, void* stream);
+
+/* mean over tokens: out[b,:] = mean_t x[b,t,:]  (cambrian_arch.py:377); bwd broadcasts. */
+int cmb_token_mean_fwd(int dtype, const void* x, int64_t B, int64_t T, int64_t D, void* out,
+                       void* stream);
+/* acc[b,t,:] (fp32) += g[b,:] / T  — backward of the mean, into the fp32 aux-feature accumulator. */
+int cmb_token_mean_bwd(int dtype, const void* g, int64_t B, int64_t T, int64_t D, float* acc,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vision-tower kernels (frozen towers: forward only; SURVEY.md §8a T1–T4)
+ * ---------------------------------------------------------------------------------------- */
+/* Non-causal multi-head self-attention over packed QKV rows (HF CLIPAttention / Dinov2 /
+ * timm Attention reached from clip_encoder.py:104, dino_encoder.py:159, siglip_encoder.py:97).
+ * qkv: [B*N, 3*heads*hd] with q|k|v column blocks; out: [B*N, heads*hd]. hd in {64, 96}
+ * (SigLIP's 72 is zero-padded to 96 by the weight packer). scale is applied to the scores.
+ * bf16 with hd in {64,96} runs the MFMA flash kernel; fp32 (and force_simple != 0) runs the
+ * one-wave-per-query VALU kernel used as the exact-fp32 parity path. */
+int cmb_vit_attn_fwd(int dtype, const void* qkv, int64_t B, int64_t N, int32_t heads, int32_t hd,
+                     float scale, void* out, int32_t force_simple, void* stream);
+
+/* Patch gather for a stride==kernel conv (ViT patch-embed 14x14/14, ConvNeXt stem 4x4/4):
+ * img NCHW [B,C,H,W] (fp32 or bf16) -> cols [B*(H/p)*(W/p), Kpad], column order (c, dy, dx),
+ * zero padded to Kpad. */
+int cmb_patchify_nchw(int in_dtype, const void* img, int64_t B, int64_t C, int64_t H, int64_t W,
+                      int32_t p, int out_dtype, void* cols, int64_t Kpad, void* stream);
+/* 2x2/2 patch gather on an NHWC map (ConvNeXt downsample): x [B,H,W,C] -> [B*(H/2)*(W/2), 4C],
+ * column order (dy, dx, c). */
+int cmb_patchify2x2_nhwc(int dtype, const void* x, int64_t B, int64_t H, int64_t W, int64_t C,
+                         void* cols, void* stream);
+/* Depthwise 7x7, pad 3, NHWC (timm ConvNeXtBlock.conv_dw): w [49, C] fp32 (tap-major), bias [C]. */
+int cmb_dwconv7x7_nhwc(int dtype, const void* x, int64_t B, int64_t H, int64_t W, int64_t C,
+                       const float* w, const float* bias, void* y, void* stream);
+/* Bilinear resample (align_corners=False, fp32 lerp) of a token grid, channels-last:
+ * in [B, Hi*Wi, C] (row stride ld_in) -> out [B, Ho*Wo, ...] written at column offset into rows
+ * of stride ld_out (so the 4 ConvNeXt stage maps land in one [B,9216,5760] buffer).
+ * replaces F.interpolate at clip_encoder.py:83-88, siglip_encoder.py:80-85, dino_encoder.py:141-146,
+ * clip_convnext_encoder.py:112-118 and the permutes around them. */
+int cmb_resample_bilinear(int dtype, const void* in, int64_t B, int32_t Hi, int32_t Wi, int64_t C,
+                          int64_t ld_in, int64_t batch_stride_in, void* out, int32_t Ho, int32_t Wo,
+                          int64_t ld_out, int64_t batch_stride_out, void* stream);
+/* Elementwise y = act(a) * b (SwiGLU: act = SiLU) / y = act(a); a,b,y [rows, D] with strides. */
+int cmb_act_mul(int dtype, int32_t act, const void* a, int64_t lda, const void* b, int64_t ldb,
+                int64_t rows, int64_t D, void* y, int64_t ldy, void* stream);
+/* dx = dy * act'(pre)  (GELU backward for the SVA / projector MLPs). */
+int cmb_act_bwd(int dtype, int32_t act, const void* dy, const void* pre, int64_t n, void* dx,
+                void* stream);
+/* dst[r*ld : r*ld+D] = src[0:D] for r in [0,nrows) — CLS-token rows of the ViT sequence buffers
+ * (the position-embedding add itself rides in the patch-embed GEMM epilogue as a row-mapped residual). */
+int cmb_bcast_rows(int dtype, void* dst, int64_t ld, int64_t nrows, int64_t D, const void* src,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMBRIAN_AMD_H */

@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly the symbols include/cambrian_amd.h declares;
+host-side guards (no CPU fallback) hold.  No kernel is launched here."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "cambrian_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cmb_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from cambrian_amd import lib
+    return lib
+
+
+def test_every_declared_symbol_is_exported_and_bound(built):
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    lib = built.load()
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in cambrian_amd.h but not exported"
+        assert s in built.SIGNATURES, f"{s} has no ctypes signature in cambrian_amd/lib.py"
+    extra = set(built.SIGNATURES) - set(syms)
+    assert not extra, f"bound but undeclared symbols: {extra}"
+    assert lib.cmb_version().decode().endswith("gfx950")
+
+
+def test_library_contains_gfx950_code_object(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built.LIB_PATH],
+                         capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_no_cpu_fallback(built):
+    from cambrian_amd import ops
+    with pytest.raises(built.CambrianAmdError):
+        ops.k_gemm(torch.zeros(4, 64), torch.zeros(8, 64))
+    from cambrian_amd.model.vision_sampler import VisionTokenSampler
+    m = VisionTokenSampler(1024, 1024, [1024], [1], 1024, 1)
+    q = torch.zeros(2, 1, 1024)
+    with pytest.raises(built.CambrianAmdError):
+        m(q, q, q, torch.ones(2, 1, dtype=torch.bool))
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    monkeypatch.setattr(built, "_lib", None)
+    monkeypatch.setattr(built, "LIB_PATH", "/nonexistent/libcambrian_amd.so")
+    with pytest.raises(built.CambrianAmdError, match="no PyTorch fallback"):
+        built.load()
+
+
+def test_state_dict_keys_match_reference_contract():
+    """SURVEY.md §8b key list (vision_sampler.py:170-175,254-267)."""
+    from cambrian_amd.model.vision_sampler import VisionTokenSampler
+    m = VisionTokenSampler(4096, 1024, [1024] * 4, [1, 1, 1, 4], 1024, 1)
+    keys = set(m.state_dict().keys())
+    want = {"layers.0.proj_context.weight", "layers.0.proj_in.weight", "layers.0.proj_out.linear_1.weight",
+            "layers.0.proj_out.linear_2.weight", "layers.0.norm.weight", "layers.0.norm.bias",
+            "layers.0.cross_attn.q_proj.0.weight", "layers.0.cross_attn.q_proj.0.bias",
+            "layers.0.cross_attn.q_proj.1.weight", "layers.0.cross_attn.o_proj.weight", "layers.0.pos_embed_3"}
+    for i in range(4):
+        for kv in "kv":
+            want |= {f"layers.0.cross_attn.{kv}_proj_{i}.0.weight", f"layers.0.cross_attn.{kv}_proj_{i}.0.bias",
+                     f"layers.0.cross_attn.{kv}_proj_{i}.1.weight"}
+    assert keys == want
+    sd = m.state_dict()
+    assert sd["layers.0.proj_in.weight"].shape == (1024, 4096 + 1024)
+    assert sd["layers.0.proj_out.linear_2.weight"].shape == (4096, 1024)
+    assert sd["layers.0.pos_embed_3"].shape == (16, 1024)
