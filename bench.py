@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py — train images/sec (fwd+bwd) of the Cambrian-8B hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input per GPU: the four frozen vision towers
+(SigLIP-SO400M/14@384, CLIP-L/14@336, DINOv2-g/14@378, ConvNeXt-XXL@1024, forward), aux projectors, 3-layer SVA
+connector, mm_projector, newline/splice, the Llama-3-8B decoder with the 10 in-LLM SVA layers, fp32 logits + loss,
+backward through everything that trains in the reference's pre-training stage (SVA + projectors; LLM and towers
+frozen, train_fsdp.py:1677-1685), gradient all-reduce (RCCL) and the AdamW update.  Workload = BASELINE.json
+configs[2] (the configuration the metric is quoted on; it fits one GPU), random-init weights, synthetic data
+(SURVEY.md §8d).  Weak scaling: the per-GPU batch is fixed.
+
+The JSON line also carries
+  roofline     — the dominant HIP kernel (the bf16 MFMA GEMM): algorithmic FLOPs of every launch in the timed region
+                 / its HIP-event duration on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline — the CPU oracle (a port of the reference's PyTorch path) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+# forward GFLOP per image of the release-8B path (BASELINE.md §2 / SURVEY.md §8d)
+TOWER_GFLOP = 381.9 + 666.4 + 1785.7 + 6334.9
+SVA_SIDE_GFLOP = 939.9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAMBRIAN_BENCH_BATCH", "8")),
+                    help="images per GPU per step (reference: per_device_train_batch_size 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (marks the line INVALID)")
+    return ap.parse_args()
+
+
+def build_model(dev, llm_layers=None):
+    from cambrian_amd.model.language_model.cambrian_llama import (CambrianLlamaForCausalLM, apply_release_8b_vision_config,
+                                                                llama3_8b_config)
+    cfg = llama3_8b_config() if llm_layers is None else llama3_8b_config(num_hidden_layers=llm_layers)
+    apply_release_8b_vision_config(cfg)
+    torch.manual_seed(0)
+    model = CambrianLlamaForCausalLM(cfg, device=dev, llm_dtype=torch.bfloat16)
+    with torch.no_grad():
+        for n, p in model.named_parameters():  # random init of that architecture (no checkpoints offline)
+            if p.device != dev:
+                continue
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+        model.model.image_newline.data = torch.randn(cfg.hidden_size) / cfg.hidden_size ** 0.5
+    model = model.to(dev)
+    for t in model.model.vision_tower_aux_list:
+        t.load_model()
+    train_keys = ("mm_projector", "pos_emb", "vision_sampler", "vision_sampler_layers", "vision_query", "image_newline")
+    for n, p in model.named_parameters():
+        p.requires_grad_(any(k in n for k in train_keys))
+    return model, cfg
+
+
+def cpu_baseline():
+    """Oracle (CPU port of the reference path) on a bounded sample: one SVA connector layer forward+backward on one
+    image's 10 944 KV tokens + one CLIP-L/14@336 tower layer forward, extrapolated by algorithmic FLOPs to a whole
+    train step of the tower+SVA path (the part the north star's roofline target is about)."""
+    from oracle import sva as OS
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    gen = torch.Generator().manual_seed(0)
+    kv_sizes, qside, hidden = [1, 1, 1, 4], 24, 1024
+    p = {k: v.requires_grad_() for k, v in OS.init_sampler_params(hidden, hidden, [hidden] * 4, kv_sizes, hidden, 1, gen).items()}
+    Bq = qside * qside
+    q = torch.randn(Bq, 1, hidden, generator=gen)
+    ctx = torch.randn(Bq, 1, hidden, generator=gen)
+    kvs = [torch.randn(Bq, s * s, hidden, generator=gen) for s in kv_sizes]
+    masks = [torch.ones(Bq, s * s, dtype=torch.bool) for s in kv_sizes]
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        out = OS.vision_token_sampler(p, q, ctx, kvs, masks)
+        out.sum().backward()
+    dt = (time.perf_counter() - t0) / reps
+    layer_gflop = 54.4 * 3.0  # fwd + bwd of one connector layer
+    gflops = layer_gflop / dt
+    step_gflop = TOWER_GFLOP + 3.0 * SVA_SIDE_GFLOP  # towers fwd + SVA side fwd+bwd, per image
+    return {"value": gflops / step_gflop, "unit": "images/s (tower+SVA part of the step)", "cores": ncores, "kind": "port",
+            "sample": f"oracle/sva.py: 1 SVA connector layer fwd+bwd, 1 image (576 queries, 10944 KV tokens), fp32, "
+                      f"{dt:.2f} s/iter = {gflops:.0f} GFLOP/s; extrapolated by algorithmic FLOPs to "
+                      f"{step_gflop:.0f} GFLOP/img (towers fwd + 3x SVA side)"}
+
+
+def main():
+    args = parse()
+    from cambrian_amd.train.dp import GradSync, init_distributed
+    rank, local, world = init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "cambrian_amd", "csrc", "libcambrian_amd.so")):
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from cambrian_amd import ops
+    from cambrian_amd.train.data_layout import synthetic_batch
+
+    model, cfg = build_model(dev, args.llm_layers)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
+    sync = GradSync(params)
+    B = args.batch
+    batch = synthetic_batch(B, seed=1234 + rank)
+    kw = dict(input_ids=batch["input_ids"].to(dev), labels=batch["labels"].to(dev),
+              position_ids=batch["position_ids"].to(dev),
+              attention_mask=None,  # square synthetic images: nothing is padded -> plain causal attention
+              images=[i.to(dev, torch.bfloat16) for i in batch["images"]],
+              image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
+              image_sizes=batch["image_sizes"])
+
+    def step():
+        out = model(**kw)
+        out.loss.backward()
+        sync.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return out.loss
+
+    for _ in range(args.warmup):
+        step()
+    prof = None
+    if not args.no_roofline and rank == 0:
+        prof = ops.GEMM_PROFILE = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        line = {
+            "metric": "train images/sec (fwd+bwd) Cambrian-8B 4-tower SVA, 576 vis-tok",
+            "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 4-tower (SigLIP-SO400M@384 + CLIP-L@336 + DINOv2-g@378 + "
+                                   "ConvNeXt-XXL@1024) + SVA (3 connector + 10 in-LLM layers) into random-init "
+                                   "Llama-3-8B, 576 visual + 24 newline tokens in a 2048-token sequence, pre-training "
+                                   "stage (SVA+projectors train, LLM+towers frozen), fwd+bwd+all-reduce+AdamW",
+                       "images_per_gpu": B, "global_batch": B * world, "seq_len": 2048,
+                       "parallelism": f"dp{world}", "loss": float(loss.item())},
+        }
+        if args.llm_layers is not None:
+            line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"
+        if prof:
+            flops = sum(f for _, _, f, dt_, _ in prof if dt_ == torch.bfloat16)
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _, dt_, _ in prof if dt_ == torch.bfloat16)
+            n = sum(1 for x in prof if x[3] == torch.bfloat16)
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16,128,128,2,2>", "achieved": ach,
+                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                                "traffic": None, "launches": n, "avg_launch_us": ms * 1e3 / max(n, 1),
+                                "gemm_share_of_step": ms / (elapsed * 1e3)}
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline must never take the measurement down
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -251,6 +251,22 @@ __global__ void __launch_bounds__(256) embed_splice_bwd_kernel(const T* __restri
   }
 }
 
+// dst[dmap(r), 0:D] = src[smap(r), 0:D]  (src == nullptr: zero fill) — row gather / scatter for the in-LLM
+// SVA hook (cambrian_llama.py:181-207) and its backward
+template <typename T>
+__global__ void __launch_bounds__(256) copy_rows_kernel(const T* __restrict__ src, RowMap smap, T* __restrict__ dst,
+                                                        RowMap dmap, int64_t rows, int D) {
+  const int nv = D >> 3;
+  const int64_t total = rows * nv;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nv;
+    const int c = (int)(i - r * nv) * 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (src) Vec8<T>::load(src + row_off(smap, (uint32_t)r) + c, v);
+    Vec8<T>::store(dst + row_off(dmap, (uint32_t)r) + c, v);
+  }
+}
+
 // dst[r, 0:D] = src[0:D] for nrows rows of stride ld (CLS token rows)
 template <typename T>
 __global__ void __launch_bounds__(256) bcast_rows_kernel(T* __restrict__ dst, int64_t ld, int64_t nrows, int D,
@@ -465,6 +481,18 @@ extern "C" int cmb_embed_splice_bwd(int dtype, const void* dout, const int32_t* 
   return CMB_OK;
 }
 
+extern "C" int cmb_copy_rows(int dtype, const void* src, const cmb_rowmap* src_map, void* dst,
+                             const cmb_rowmap* dst_map, int64_t rows, int64_t D, void* stream) {
+  if (!dst || !dst_map || (src && !src_map) || rows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  cmb_rowmap ident = {0, 1, 0, 0, D};
+  const RowMap sm = make_rowmap(src ? *src_map : ident), dm = make_rowmap(*dst_map);
+  DT_SWITCH(dtype, hipLaunchKernelGGL(copy_rows_kernel<T>, dim3(grid_for(rows * (D / 8), 256, 16384)), dim3(256), 0,
+                                      (hipStream_t)stream, (const T*)src, sm, (T*)dst, dm, rows, (int)D));
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
 extern "C" int cmb_bcast_rows(int dtype, void* dst, int64_t ld, int64_t nrows, int64_t D, const void* src,
                               void* stream) {
   if (!dst || !src || nrows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
@@ -477,7 +505,9 @@ extern "C" int cmb_bcast_rows(int dtype, void* dst, int64_t ld, int64_t nrows, i
 
 extern "C" int cmb_patchify_nchw(int in_dtype, const void* img, int64_t B, int64_t C, int64_t H, int64_t W, int32_t p,
                                  int out_dtype, void* cols, int64_t Kpad, void* stream) {
-  if (!img || !cols || B < 0 || C <= 0 || p <= 0 || H % p || W % p || Kpad < C * p * p) return CMB_ERR_BAD_ARG;
+  // H, W need not be multiples of p: like a stride-p convolution the trailing H % p rows / columns are
+  // dropped (SigLIP-SO400M runs 384 px with 14 px patches -> 27 x 27)
+  if (!img || !cols || B < 0 || C <= 0 || p <= 0 || H < p || W < p || Kpad < C * p * p) return CMB_ERR_BAD_ARG;
   if (B == 0) return CMB_OK;
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = B * (H / p) * (W / p) * Kpad;

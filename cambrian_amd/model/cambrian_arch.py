@@ -1,0 +1,272 @@
+"""Multimodal glue on the MI355X kernels — drop-in for ``cambrian/model/cambrian_arch.py``.
+
+Same mixins, method names, argument lists, 10-tuple return and state-dict keys as the reference
+(``CambrianMetaModel:33``, ``initialize_vision_modules:99``, ``CambrianMetaForCausalLM:259``,
+``rearrange_vision_tower_features_train:271``, ``encode_images:332``, ``prepare_inputs_labels_for_multimodal:340``).
+The static ("XLA"/training) branch — the hot path of the north star — is implemented; it is selected by
+``cambrian_amd.model.STATIC_PATH`` instead of ``torch_xla`` being importable (SURVEY.md §8b "path switch").
+The dynamic eval/generate branch (:388-390,422-451,492-609) is the next row and raises.
+
+MI355X-first differences inside the same contract:
+  * aux features stay in tower-token-major layout; the window partition of :271-287 is folded into the SVA
+    attention kernel's index arithmetic (nothing is permuted or copied, bit-exact gather);
+  * the global context is kept as one row per image ([B,1024]) and broadcast in a GEMM epilogue;
+  * newline column + image-token splice + embedding lookup are one gather kernel (:413-420,457-490);
+  * with ``config.sva_fused = True`` (default) the 7th..10th return values carry the compact fused-path
+    tensors (``SvaContext``) consumed by ``cambrian_llama.py`` here; with ``False`` they are the reference's
+    window-major lists, so an unmodified reference decoder wrapper can consume them.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import lib as L
+from .. import ops
+from ..constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+from .multimodal_encoder.builder import build_vision_tower_aux_list
+from .multimodal_projector.builder import HipSequential, build_vision_projector
+from .vision_sampler import VisionTokenSampler
+
+# static (fixed 2048-token layout, train) vs dynamic (eval/generate) path; replaces `IS_XLA_AVAILABLE`
+# (cambrian/utils.py:17-22) which cannot be the switch on a machine without torch_xla.
+STATIC_PATH = True
+
+
+@dataclass
+class SvaContext:
+    """What the in-LLM SVA layers need (cambrian_llama.py:168-207), in the fused layout."""
+    feats: List[torch.Tensor]                 # [B*T_i, C] tower-token-major, wrapped by shared_grad
+    masks_u8: List[Optional[torch.Tensor]]    # uint8 [B*side*side, r_i*r_i]
+    holders: List[ops.GradAccumulator]
+    ctx_b: torch.Tensor                       # [B, C] global context, one row per image
+    B: int
+    side: int
+
+
+def _sva_modules(owner: nn.Module, config, vision_tower_aux_list, hidden_size: int):
+    """Shared by __init__ (config-driven, cambrian_arch.py:41-79) and initialize_vision_modules (:142-169)."""
+    vh = config.vision_hidden_size
+    n_group = config.num_query_group
+    query_num_list = config.query_num_list
+    token_lens = config.mm_vision_tower_aux_token_len_list
+    image_token_len = config.image_token_len
+    owner.mm_projector = HipSequential(nn.Linear(vh * n_group, hidden_size), nn.GELU(), nn.Linear(hidden_size, hidden_size))
+    for aux_i, tower in enumerate(vision_tower_aux_list):
+        setattr(owner, f"mm_projector_aux_{aux_i}",
+                HipSequential(nn.Linear(tower.hidden_size, vh), nn.GELU(), nn.Linear(vh, vh), nn.LayerNorm(vh)))
+    n_towers = len(vision_tower_aux_list)
+    for g in range(n_group):
+        sizes = [int(t ** 0.5) // int(query_num_list[g] ** 0.5) for t in token_lens]
+        setattr(owner, f"vision_sampler_{g}", VisionTokenSampler(vh, vh, [vh] * n_towers, sizes, vh, config.connector_depth))
+    if not config.connector_only:
+        sizes = [int(t ** 0.5) // int(image_token_len ** 0.5) for t in token_lens]
+        owner.vision_sampler_layers = nn.ModuleList(
+            [VisionTokenSampler(hidden_size, vh, [vh] * n_towers, sizes, vh, 1)
+             for _ in range(config.num_of_vision_sampler_layers)])
+
+
+class CambrianMetaModel:
+    """cambrian_arch.py:33-200."""
+
+    def __init__(self, config):
+        super(CambrianMetaModel, self).__init__(config)
+        if hasattr(config, "mm_vision_tower_aux_list"):
+            projector_type = getattr(config, "mm_projector_type", "linear")
+            self.vision_tower_aux_list = build_vision_tower_aux_list(config, delay_load=True)
+            if projector_type == "sva":
+                _sva_modules(self, config, self.vision_tower_aux_list, config.hidden_size)
+                self.vision_query = nn.Parameter(torch.randn((config.num_query_group, config.vision_hidden_size), dtype=self.dtype))
+                self.image_newline = nn.Parameter(torch.empty(config.hidden_size, dtype=self.dtype))
+            else:
+                config.mm_hidden_size = sum(t.hidden_size for t in self.vision_tower_aux_list)
+                self.mm_projector = build_vision_projector(config)
+                self.image_newline = nn.Parameter(torch.empty(config.hidden_size, dtype=self.dtype))
+
+    def get_vision_tower_aux_list(self):
+        return getattr(self, "vision_tower_aux_list", None)
+
+    def initialize_vision_modules(self, model_args, fsdp=None):
+        cfg = self.config
+        cfg.image_token_len = model_args.image_token_len
+        cfg.num_query_group = model_args.num_query_group
+        cfg.query_num_list = model_args.query_num_list
+        assert model_args.num_query_group == len(model_args.query_num_list)
+        cfg.connector_depth = model_args.connector_depth
+        cfg.mm_vision_tower_aux_list = model_args.vision_tower_aux_list
+        cfg.mm_vision_tower_aux_token_len_list = model_args.vision_tower_aux_token_len_list
+        cfg.connector_only = model_args.connector_only
+
+        if self.get_vision_tower_aux_list() is None:
+            towers = build_vision_tower_aux_list(model_args)
+            # frozen towers are deliberately NOT registered sub-modules (cambrian_arch.py:125-128)
+            self.vision_tower_aux_list = nn.ModuleList(towers) if model_args.unfreeze_mm_vision_tower else towers
+        else:
+            towers = self.vision_tower_aux_list
+            for t in towers:
+                t.load_model()
+
+        cfg.use_mm_proj = True
+        cfg.mm_projector_type = getattr(model_args, "mm_projector_type", "linear")
+        cfg.vision_hidden_size = model_args.vision_hidden_size
+        cfg.mm_vision_select_layer = model_args.mm_vision_select_layer
+        cfg.mm_vision_select_feature = model_args.mm_vision_select_feature
+
+        if getattr(self, "mm_projector", None) is None:
+            if cfg.mm_projector_type == "sva":
+                if not cfg.connector_only:
+                    cfg.num_of_vision_sampler_layers = model_args.num_of_vision_sampler_layers
+                    cfg.start_of_vision_sampler_layers = model_args.start_of_vision_sampler_layers
+                    cfg.stride_of_vision_sampler_layers = model_args.stride_of_vision_sampler_layers
+                _sva_modules(self, cfg, towers, cfg.hidden_size)
+                vision_embed_std = 1 / torch.sqrt(torch.tensor(cfg.vision_hidden_size, dtype=self.dtype))
+                self.vision_query = nn.Parameter(
+                    torch.randn((cfg.num_query_group, cfg.vision_hidden_size), dtype=self.dtype) * vision_embed_std)
+            else:
+                cfg.mm_hidden_size = sum(t.hidden_size for t in towers)
+                self.mm_projector = build_vision_projector(cfg)
+            embed_std = 1 / torch.sqrt(torch.tensor(cfg.hidden_size, dtype=self.dtype))
+            self.image_newline = nn.Parameter(torch.randn(cfg.hidden_size, dtype=self.dtype) * embed_std)
+        else:
+            for p in self.mm_projector.parameters():  # in case it is frozen by LoRA
+                p.requires_grad = True
+
+        pretrain = getattr(model_args, "pretrain_mm_mlp_adapter", None)
+        if pretrain is not None:
+            weights = torch.load(pretrain, map_location="cpu")
+
+            def get_w(w, keyword):
+                return {k.split(keyword + ".")[1]: v for k, v in w.items() if keyword + "." in k}
+
+            self.mm_projector.load_state_dict(get_w(weights, "mm_projector"), strict=True)
+            if cfg.mm_projector_type == "sva":
+                for aux_i in range(len(towers)):
+                    getattr(self, f"mm_projector_aux_{aux_i}").load_state_dict(get_w(weights, f"mm_projector_aux_{aux_i}"), strict=True)
+                for g in range(cfg.num_query_group):
+                    getattr(self, f"vision_sampler_{g}").load_state_dict(get_w(weights, f"vision_sampler_{g}"), strict=True)
+                if not cfg.connector_only:
+                    self.vision_sampler_layers.load_state_dict(get_w(weights, "vision_sampler_layers"), strict=True)
+                self.vision_query.data = weights["model.vision_query"]
+            self.image_newline.data = weights["model.image_newline"]
+
+
+class CambrianMetaForCausalLM(ABC):
+    """cambrian_arch.py:259-653 (static path)."""
+
+    @abstractmethod
+    def get_model(self):
+        pass
+
+    def get_vision_tower_aux_list(self):
+        return self.get_model().get_vision_tower_aux_list()
+
+    def rearrange_vision_tower_features_train(self, vision_tower_aux_feature_list, vision_tower_aux_attention_masks_list,
+                                              query_side_len):
+        """cambrian_arch.py:271-287 — kept for API compatibility (``sva_fused=False``): window-major copies.
+        The fused path never calls this; its consumers do the same gather by index arithmetic."""
+        feats, masks = [], []
+        bs = vision_tower_aux_feature_list[0].shape[0]
+        for f, m in zip(vision_tower_aux_feature_list, vision_tower_aux_attention_masks_list):
+            side = int(f.shape[1] ** 0.5)
+            assert (side // query_side_len) * query_side_len == side
+            r = side // query_side_len
+            f = f.view(bs, query_side_len, r, query_side_len, r, -1).permute(0, 1, 3, 2, 4, 5).contiguous()
+            feats.append(f.flatten(0, 2).flatten(1, 2))
+            masks.append(m.view(bs * query_side_len * query_side_len, r * r))
+        return feats, masks
+
+    def rearrange_vision_tower_features_inference(self, vision_tower_aux_feature_list, query_side_len, image_sizes,
+                                                  unpad=False):
+        raise NotImplementedError("dynamic (eval/generate) path: SURVEY.md §8f N1, not part of the training hot path")
+
+    def encode_images(self, image_aux_list):
+        towers = self.get_model().get_vision_tower_aux_list()
+        return [tower(image_aux) for image_aux, tower in zip(image_aux_list, towers)]
+
+    # ------------------------------------------------------------------------------------------
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels,
+                                             images, image_aux_attention_masks_list=None, image_sizes=None):
+        model = self.get_model()
+        towers = model.get_vision_tower_aux_list()
+        if towers is None or images is None or input_ids.shape[1] == 1:  # cambrian_arch.py:346-347
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels, None, None, None, None
+        if not STATIC_PATH:
+            raise NotImplementedError("dynamic (eval/generate) path: SURVEY.md §8f N1")
+        cfg = model.config
+        if getattr(cfg, "tune_mm_mlp_adapter", False) and getattr(cfg, "mm_use_im_start_end", False):
+            raise NotImplementedError  # cambrian_arch.py:454-455
+
+        image_aux_list = images
+        bs = image_aux_list[0].shape[0]
+        dtype = image_aux_list[0].dtype
+        image_token_len = cfg.image_token_len
+        side = int(image_token_len ** 0.5)
+        feats_raw = self.encode_images(image_aux_list)                              # :366
+
+        sva_ctx = None
+        if cfg.mm_projector_type == "sva":
+            vh = cfg.vision_hidden_size
+            feats, holders = [], []
+            for aux_i in range(len(towers)):                                         # :372-379
+                f = feats_raw[aux_i]
+                f = getattr(model, f"mm_projector_aux_{aux_i}")(f.to(dtype)).to(dtype)
+                holders.append(ops.GradAccumulator())
+                f2 = f.reshape(-1, vh)
+                feats.append(ops.shared_grad(f2, holders[-1]) if f2.requires_grad else f2)
+            T0 = feats_raw[0].shape[1]
+            ctx_b = ops.token_mean(feats[0].view(bs, T0, vh), holders[0] if feats[0].requires_grad else None)  # [B, C] (:377)
+            masks_u8 = self._masks_u8(image_aux_attention_masks_list, bs, side, feats)
+            group_out = []
+            for g, query_num in enumerate(cfg.query_num_list):                       # :382-402
+                qside = int(query_num ** 0.5)
+                if qside != side:
+                    raise NotImplementedError("query groups with query_num != image_token_len need the bilinear "
+                                              "resize backward (cambrian_arch.py:395-401); not used by any release config")
+                vq = model.vision_query[g].to(dtype)
+                q2 = vq.view(1, vh).expand(bs * query_num, vh).contiguous()
+                out = getattr(model, f"vision_sampler_{g}").forward_fused(q2, ctx_b, feats, masks_u8, holders, bs, qside)
+                group_out.append(out)
+            image_features = group_out[0] if len(group_out) == 1 else torch.cat(group_out, -1)
+            sva_ctx = SvaContext(feats, masks_u8, holders, ctx_b, bs, side)
+        else:
+            image_features = torch.cat(feats_raw, -1).to(dtype)                      # :408-410
+            image_features = image_features.reshape(-1, image_features.shape[-1])
+
+        image_features = model.mm_projector(image_features).to(dtype)               # :411   [B*side*side, H]
+        H = image_features.shape[-1]
+        # newline column + splice into the token embeddings: one gather kernel (:413-420, :457-490)
+        inputs_embeds, _pos = ops.embed_splice(input_ids, model.embed_tokens.weight, image_features.view(bs, side * side, H),
+                                               model.image_newline, side, IMAGE_TOKEN_INDEX)
+        final_size = [(side, side)] * bs
+        if sva_ctx is None:
+            return None, position_ids, attention_mask, past_key_values, inputs_embeds, labels, None, None, final_size, None
+        if getattr(cfg, "sva_fused", True):
+            return (None, position_ids, attention_mask, past_key_values, inputs_embeds, labels,
+                    sva_ctx, sva_ctx.masks_u8, final_size, sva_ctx.ctx_b)
+        # reference-format lists (window-major) for an unmodified reference decoder wrapper (:404-406)
+        f3 = [f.view(bs, -1, f.shape[-1]) for f in sva_ctx.feats]
+        kv_final, m_final = self.rearrange_vision_tower_features_train(f3, image_aux_attention_masks_list, side)
+        ctx_final = sva_ctx.ctx_b[:, None, None, :].expand(-1, side * side, 1, -1).flatten(0, 1)
+        return None, position_ids, attention_mask, past_key_values, inputs_embeds, labels, kv_final, m_final, final_size, ctx_final
+
+    @staticmethod
+    def _masks_u8(mask_list, bs: int, side: int, feats: Sequence[torch.Tensor]):
+        """Collator masks are bool [B, side*side, r*r] already window-major per query (train_fsdp.py:1127-1137,
+        1164); the kernel reads them as uint8 [B*side*side, r*r].  None -> all keys visible."""
+        if mask_list is None:
+            return [None] * len(feats)
+        out = []
+        for m in mask_list:
+            m2 = m.reshape(bs * side * side, -1).contiguous()
+            out.append(m2.view(torch.uint8) if m2.dtype == torch.bool else m2.to(torch.uint8))
+        return out
+
+    def initialize_vision_tokenizer(self, model_args, tokenizer):
+        """cambrian_arch.py:611-653.  The release configs use neither extra patch nor start/end tokens
+        (scripts/cambrian/*.sh: --mm_use_im_start_end False --mm_use_im_patch_token False): nothing to resize."""
+        if getattr(model_args, "mm_use_im_patch_token", False) or getattr(model_args, "mm_use_im_start_end", False):
+            raise NotImplementedError("extra image tokens are not used by any Cambrian-1 release config")

@@ -1,0 +1,253 @@
+"""Cambrian-Llama on MI355X — counterpart of ``cambrian/model/language_model/cambrian_llama.py``.
+
+What is on the hot path here:
+  * the in-LLM SVA hook (:168-207, static branch): after decoder layer ``start + k*stride`` the 576 latent-query
+    rows of ``hidden[:, image_position : image_position+600]`` (24x25 grid, newline column skipped) go through
+    ``vision_sampler_layers[k]`` and are written back in place — one strided gather kernel, the fused SVA layer,
+    one strided scatter kernel;
+  * RMSNorm (the reference's patched fp32 version, train_fsdp.py:1429-1438) and RoPE as HIP kernels;
+  * fp32 logits + shifted cross-entropy exactly as :402-422.
+The decoder's own GEMMs / causal attention stay stock PyTorch-ROCm (hipBLASLt, SDPA) per the north star; the
+reference file's decoder loop is written against the transformers==4.37 tuple API and does not run on the installed
+transformers 5.x, so the loop is re-stated here with HF-compatible parameter names
+(``model.layers.{i}.self_attn.q_proj.weight`` ...).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+try:  # HF config class only (no HF modelling code is used)
+    from transformers import LlamaConfig
+    from transformers.modeling_outputs import CausalLMOutputWithPast
+except Exception:  # pragma: no cover - transformers is part of the image
+    LlamaConfig = object
+    CausalLMOutputWithPast = None
+
+from ... import ops
+from ...constants import IGNORE_INDEX
+from ..cambrian_arch import CambrianMetaForCausalLM, CambrianMetaModel, SvaContext
+
+
+class CambrianConfig(LlamaConfig):
+    model_type = "cambrian_llama"
+    debug = "debug"
+
+
+class HipRMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6, device=None, dtype=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        return ops.rmsnorm(x, self.weight, self.variance_epsilon)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, cfg, device, dtype):
+        super().__init__()
+        kw = dict(bias=False, device=device, dtype=dtype)
+        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, **kw)
+        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, **kw)
+        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, **kw)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, cfg, device, dtype):
+        super().__init__()
+        self.nh, self.nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        kw = dict(bias=getattr(cfg, "attention_bias", False), device=device, dtype=dtype)
+        self.q_proj = nn.Linear(cfg.hidden_size, self.nh * self.hd, **kw)
+        self.k_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, **kw)
+        self.v_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, **kw)
+        self.o_proj = nn.Linear(self.nh * self.hd, cfg.hidden_size, **kw)
+
+    def forward(self, x, cos, sin, attn_mask):
+        B, S, _ = x.shape
+        q = ops.rope(self.q_proj(x).view(B * S, self.nh, self.hd), cos, sin).view(B, S, self.nh, self.hd).transpose(1, 2)
+        k = ops.rope(self.k_proj(x).view(B * S, self.nkv, self.hd), cos, sin).view(B, S, self.nkv, self.hd).transpose(1, 2)
+        v = self.v_proj(x).view(B, S, self.nkv, self.hd).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
+                                           enable_gqa=self.nkv != self.nh)
+        return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, cfg, device, dtype):
+        super().__init__()
+        self.self_attn = LlamaAttention(cfg, device, dtype)
+        self.mlp = LlamaMLP(cfg, device, dtype)
+        self.input_layernorm = HipRMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device, dtype)
+        self.post_attention_layernorm = HipRMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device, dtype)
+
+    def forward(self, x, cos, sin, attn_mask):
+        x = x + self.self_attn(self.input_layernorm(x), cos, sin, attn_mask)
+        return x + self.mlp(self.post_attention_layernorm(x))
+
+
+class LlamaBackbone(nn.Module):
+    """HF ``LlamaModel`` parameter layout (embed_tokens / layers / norm), minimal forward."""
+
+    def __init__(self, config, device=None, llm_dtype=torch.bfloat16):
+        super().__init__()
+        self.config = config
+        self.llm_dtype = llm_dtype
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, device=device, dtype=llm_dtype)
+        self.layers = nn.ModuleList([LlamaDecoderLayer(config, device, llm_dtype) for _ in range(config.num_hidden_layers)])
+        self.norm = HipRMSNorm(config.hidden_size, config.rms_norm_eps, device, llm_dtype)
+
+    @property
+    def dtype(self):
+        """dtype for NEW trainable parameters (vision_query, image_newline): fp32 masters, as in the reference
+        run where parameters are fp32 and only the compute is bf16 (fsdp_config.json:6, train_fsdp.py:1267-1398)."""
+        return torch.float32
+
+
+class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
+    config_class = CambrianConfig
+
+    def __init__(self, config, device=None, llm_dtype=torch.bfloat16):
+        # CambrianMetaModel.__init__ -> super().__init__(config) -> LlamaBackbone.__init__(config)
+        self._ctor_kw = (device, llm_dtype)
+        LlamaBackbone.__init__(self, config, device, llm_dtype)
+        if hasattr(config, "mm_vision_tower_aux_list"):
+            # re-run the mixin's config-driven construction on the already initialised backbone
+            _BackboneShim.attach(self, config)
+
+    def forward(self, inputs_embeds: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
+                attention_mask: Optional[torch.Tensor] = None, sva: Optional[SvaContext] = None) -> torch.Tensor:
+        cfg = self.config
+        B, S, H = inputs_embeds.shape
+        dev = inputs_embeds.device
+        if position_ids is None:
+            position_ids = torch.arange(S, device=dev).unsqueeze(0).expand(B, S)
+        hd = self.layers[0].self_attn.hd
+        cos, sin = ops.rope_table(position_ids, hd, float(getattr(cfg, "rope_theta", 10000.0)))
+        attn_mask = None
+        if attention_mask is not None:
+            causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril_()
+            attn_mask = causal[None, None] & attention_mask.to(torch.bool)[:, None, None, :]
+            # a fully masked query row would be NaN in SDPA; padded rows attend to themselves (their loss is ignored)
+            attn_mask = attn_mask | torch.eye(S, dtype=torch.bool, device=dev)[None, None]
+        hidden = inputs_embeds
+        hook_layers = {}
+        if sva is not None and not getattr(cfg, "connector_only", True):
+            start, stride = cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers
+            hook_layers = {start + k * stride: k for k in range(len(self.vision_sampler_layers))}  # :170-172
+        for i, layer in enumerate(self.layers):
+            hidden = layer(hidden, cos, sin, attn_mask)
+            if i in hook_layers:
+                hidden = self._sva_hook(hidden, hook_layers[i], sva)
+        return self.norm(hidden)
+
+    def _sva_hook(self, hidden: torch.Tensor, k: int, sva: SvaContext) -> torch.Tensor:
+        """cambrian_llama.py:177-207 (static branch)."""
+        cfg = self.config
+        p0 = cfg.image_position
+        side = int(cfg.image_token_len ** 0.5)
+        hidden = hidden if hidden.is_contiguous() else hidden.contiguous()
+        q2 = ops.gather_query_rows(hidden, p0, side)                                   # [B*576, H]
+        feats = [f if f.dtype == q2.dtype else f.to(q2.dtype) for f in sva.feats]      # :186
+        out = self.vision_sampler_layers[k].forward_fused(q2, sva.ctx_b.to(q2.dtype), feats, sva.masks_u8, sva.holders,
+                                                         sva.B, side)
+        return ops.scatter_query_rows(hidden, out, p0, side)
+
+
+class _BackboneShim:
+    """CambrianMetaModel.__init__ calls ``super().__init__(config)`` (it is written as a mixin placed before the HF
+    model class).  Our backbone is already constructed when we need the mixin's body, so run that body with a
+    no-op super().__init__."""
+
+    @staticmethod
+    def attach(model: "CambrianLlamaModel", config):
+        from ..cambrian_arch import _sva_modules, build_vision_projector, build_vision_tower_aux_list
+        projector_type = getattr(config, "mm_projector_type", "linear")
+        model.vision_tower_aux_list = build_vision_tower_aux_list(config, delay_load=True)
+        if projector_type == "sva":
+            _sva_modules(model, config, model.vision_tower_aux_list, config.hidden_size)
+            model.vision_query = nn.Parameter(torch.randn((config.num_query_group, config.vision_hidden_size), dtype=model.dtype))
+        else:
+            config.mm_hidden_size = sum(t.hidden_size for t in model.vision_tower_aux_list)
+            model.mm_projector = build_vision_projector(config)
+        model.image_newline = nn.Parameter(torch.empty(config.hidden_size, dtype=model.dtype))
+
+
+class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
+    config_class = CambrianConfig
+
+    def __init__(self, config, device=None, llm_dtype=torch.bfloat16):
+        super().__init__()
+        self.config = config
+        self.model = CambrianLlamaModel(config, device, llm_dtype)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False, device=device, dtype=llm_dtype)
+
+    def get_model(self):
+        return self.model
+
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                image_aux_attention_masks_list=None, image_sizes=None, return_dict=None, cache_position=None):
+        sva = None
+        if inputs_embeds is None:  # cambrian_llama.py:315-336
+            (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels, sva, _masks, _final_size,
+             _ctx) = self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
+                                                               labels, images, image_aux_attention_masks_list, image_sizes)
+            if inputs_embeds is None:  # text-only early-out (cambrian_arch.py:346-347)
+                inputs_embeds = self.model.embed_tokens(input_ids)
+        if sva is not None and not isinstance(sva, SvaContext):
+            raise TypeError("this decoder consumes the fused SvaContext (config.sva_fused = True)")
+        hidden = self.model(inputs_embeds.to(self.model.llm_dtype), position_ids, attention_mask, sva)
+        logits = self.lm_head(hidden).float()                                        # :402-409
+        loss = None
+        if labels is not None:                                                       # :411-422
+            shift_logits = logits[..., :-1, :].contiguous().view(-1, self.vocab_size)
+            shift_labels = labels[..., 1:].contiguous().view(-1).to(shift_logits.device)
+            loss = F.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX)
+        if CausalLMOutputWithPast is not None:
+            return CausalLMOutputWithPast(loss=loss, logits=logits)
+        return {"loss": loss, "logits": logits}
+
+
+def llama3_8b_config(**overrides) -> CambrianConfig:
+    """Meta-Llama-3-8B-Instruct geometry (the LLM of Cambrian-8B, scripts/cambrian/pretrain_cambrian_8b.sh:12)."""
+    kw = dict(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+              num_key_value_heads=8, rms_norm_eps=1e-5, rope_theta=500000.0, max_position_embeddings=8192)
+    kw.update(overrides)
+    return CambrianConfig(**kw)
+
+
+def apply_release_8b_vision_config(cfg, towers: Optional[List[str]] = None, token_lens: Optional[List[int]] = None):
+    """scripts/cambrian/pretrain_cambrian_8b.sh:15-27 copied onto the config as train_fsdp.py:1671-1709 does."""
+    cfg.mm_vision_tower_aux_list = towers or ["siglip/CLIP-ViT-SO400M-14-384", "openai/clip-vit-large-patch14-336",
+                                              "facebook/dinov2-giant-res378", "clip-convnext-XXL-multi-stage"]
+    cfg.mm_vision_tower_aux_token_len_list = token_lens or [576, 576, 576, 9216]
+    cfg.image_token_len = 576
+    cfg.num_query_group = 1
+    cfg.query_num_list = [576]
+    cfg.connector_depth = 3
+    cfg.vision_hidden_size = 1024
+    cfg.connector_only = False
+    cfg.num_of_vision_sampler_layers = 10
+    cfg.start_of_vision_sampler_layers = 0
+    cfg.stride_of_vision_sampler_layers = 3
+    cfg.mm_projector_type = "sva"
+    cfg.image_position = 91
+    cfg.mm_vision_select_layer = -2
+    cfg.mm_vision_select_feature = "patch"
+    cfg.unfreeze_mm_vision_tower = False
+    cfg.sva_fused = True
+    return cfg

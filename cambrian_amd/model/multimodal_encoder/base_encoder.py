@@ -1,0 +1,149 @@
+"""Tower protocol of the reference (cambrian/model/multimodal_encoder/base_encoder.py:12-134): same attribute
+and property names, so cambrian_arch / the train harness can treat these towers exactly like the originals.
+The arithmetic lives in ``vit.py`` / ``convnext.py`` (HIP kernels); there is no HF/timm module inside."""
+from __future__ import annotations
+
+import logging
+import os
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+logger = logging.getLogger("cambrian_amd")
+
+OPENAI_CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
+OPENAI_CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
+
+
+class ProcessorWrapper:
+    """base_encoder.py:12-30 — wraps a callable transform behind the HF image-processor protocol."""
+
+    def __init__(self, transform, height=378, width=378, image_mean=OPENAI_CLIP_MEAN):
+        self._crop_size = {"height": height, "width": width}
+        self._transforms = transform
+        self.image_mean = image_mean
+
+    @property
+    def crop_size(self):
+        return self._crop_size
+
+    def preprocess(self, image, return_tensors="pt"):
+        return {"pixel_values": [self._transforms(image)]}
+
+
+class SimpleImageTransform:
+    """Resize (bicubic) to size x size and normalise: the offline stand-in for CLIPImageProcessor / the
+    open_clip transform (no network to fetch their configs).  Pre-processing is CPU work outside the hot path
+    (SURVEY.md §2 row 15)."""
+
+    def __init__(self, size: int, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD):
+        self.size, self.mean, self.std = size, mean, std
+
+    def __call__(self, image):
+        import numpy as np
+        img = image.convert("RGB").resize((self.size, self.size), resample=3)
+        x = torch.from_numpy(np.asarray(img).copy()).float().div_(255.0).permute(2, 0, 1)
+        mean = torch.tensor(self.mean).view(3, 1, 1)
+        std = torch.tensor(self.std).view(3, 1, 1)
+        return (x - mean) / std
+
+
+class BaseVisionTower(nn.Module):
+    """base_encoder.py:33-134."""
+
+    def __init__(self, vision_tower_name, args, delay_load=False):
+        super().__init__()
+        self.is_loaded = False
+        self.args = args
+        self.vision_tower_name = vision_tower_name
+        self.select_layer = getattr(args, "mm_vision_select_layer", -2)
+        self.select_feature = getattr(args, "mm_vision_select_feature", "patch")
+        self.unfreeze_mm_vision_tower = getattr(args, "unfreeze_mm_vision_tower", False)
+        self.delay_load = delay_load
+        self._interp_size = None
+        if self.unfreeze_mm_vision_tower:
+            raise NotImplementedError("unfrozen vision towers need the tower backward kernels "
+                                      "(SURVEY.md §8f N4); the reference default is frozen")
+
+    # -- subclasses ------------------------------------------------------------------------------
+    def load_model(self, device_map=None):
+        raise NotImplementedError("Subclasses must implement load_model")
+
+    def _forward(self, images):
+        raise NotImplementedError("Subclasses must implement forward")
+
+    def forward(self, images):
+        if type(images) is list:  # base_encoder.py:55-64
+            return [self._forward(image.unsqueeze(0)) for image in images]
+        return self._forward(images)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    @staticmethod
+    def _seed_for(name: str) -> int:
+        return int.from_bytes(name.encode()[:8].ljust(8, b"\0"), "little") % (2 ** 31)
+
+    def _target_device(self):
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    @property
+    def dummy_feature(self):
+        return torch.zeros(1, self.hidden_size, device=self.device, dtype=self.dtype)
+
+    @property
+    def dtype(self):
+        vt = getattr(self, "vision_tower", None)
+        return vt.compute_dtype if vt is not None else torch.float32
+
+    @property
+    def device(self):
+        vt = getattr(self, "vision_tower", None)
+        if vt is not None:
+            for b in vt.buffers():
+                return b.device
+        return torch.device("cpu")
+
+    @property
+    def config(self):
+        return self.cfg_only
+
+    @property
+    def hidden_size(self):
+        return self._hidden_size
+
+    @property
+    def image_size(self):
+        return self._image_size
+
+    @property
+    def patch_size(self):
+        return self._patch_size
+
+    @property
+    def num_patches_per_side(self):
+        if self._interp_size is not None:
+            return int(self._interp_size ** 0.5)
+        return self.image_size // self.patch_size
+
+    @property
+    def num_patches(self):
+        if self._interp_size is not None:
+            return self._interp_size
+        return self.num_patches_per_side ** 2
+
+    def to(self, *args, **kwargs):
+        """The reference moves frozen towers with ``.to(dtype=bf16, device=...)`` (train_fsdp.py:1659); the packed
+        weights are re-created in the requested dtype because packing (padding, K-step) depends on it."""
+        dtype = kwargs.get("dtype")
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+        out = super().to(*args, **kwargs)
+        if dtype is not None and self.is_loaded and dtype != self.vision_tower.compute_dtype:
+            dev = self.device
+            self.is_loaded = False
+            self._compute_dtype = dtype
+            self.load_model()
+            self.vision_tower.to(dev)
+        return out

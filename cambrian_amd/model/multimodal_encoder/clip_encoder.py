@@ -1,0 +1,89 @@
+"""OpenAI-CLIP tower wrapper — drop-in for cambrian/model/multimodal_encoder/clip_encoder.py:13-107."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+from .base_encoder import BaseVisionTower, ProcessorWrapper, SimpleImageTransform, logger
+from .vit import ViTConfig, ViTTrunk, resample_tokens
+
+# architecture table (no network: the HF config.json files cannot be fetched)
+CLIP_ARCH = {
+    "openai/clip-vit-large-patch14-336": dict(image_size=336, patch_size=14, hidden_size=1024, num_layers=24,
+                                              num_heads=16, mlp_dim=4096),
+    "openai/clip-vit-large-patch14": dict(image_size=224, patch_size=14, hidden_size=1024, num_layers=24,
+                                          num_heads=16, mlp_dim=4096),
+    "openai/clip-vit-base-patch16": dict(image_size=224, patch_size=16, hidden_size=768, num_layers=12,
+                                         num_heads=12, mlp_dim=3072),
+    "openai/clip-vit-base-patch32": dict(image_size=224, patch_size=32, hidden_size=768, num_layers=12,
+                                         num_heads=12, mlp_dim=3072),
+}
+
+
+def extract_interp(model_name):
+    """clip_encoder.py:13-25."""
+    interp = None
+    base_model_name = model_name
+    if "interp" in model_name:
+        base_model_name = model_name.split("-interp")[0]
+    for part in model_name.split("-"):
+        if part.startswith("interp"):
+            interp = int(part[6:])
+    return base_model_name, interp
+
+
+class ClipVisionTower(BaseVisionTower):
+    def __init__(self, vision_tower_name, args, delay_load=False):
+        super().__init__(vision_tower_name, args, delay_load)
+        base_model_name, interp = extract_interp(vision_tower_name)
+        self.vision_tower_name = base_model_name
+        self._interp_size = interp
+        self._set_arch()
+        if not self.delay_load:
+            self.load_model()
+
+    def _set_arch(self):
+        if self.vision_tower_name not in CLIP_ARCH:
+            raise ValueError(f"Unknown vision tower: {self.vision_tower_name}")
+        a = CLIP_ARCH[self.vision_tower_name]
+        self._arch = a
+        self._hidden_size, self._image_size, self._patch_size = a["hidden_size"], a["image_size"], a["patch_size"]
+        self.cfg_only = SimpleNamespace(hidden_size=a["hidden_size"], image_size=a["image_size"],
+                                        patch_size=a["patch_size"], num_hidden_layers=a["num_layers"])
+
+    def _vit_config(self) -> ViTConfig:
+        a = self._arch
+        # hidden_states[select_layer] (clip_encoder.py:66): index L+1+select_layer of [emb, l1..lL]
+        run = a["num_layers"] + 1 + self.select_layer if self.select_layer < 0 else self.select_layer
+        return ViTConfig(act="quick_gelu", ln_eps=1e-5, has_cls=True, pre_ln=True, final_ln=False, patch_bias=False,
+                         run_layers=run, **a)
+
+    def load_model(self, device_map=None):
+        if self.is_loaded:
+            logger.debug(f"{self.vision_tower_name} is already loaded, `load_model` called again, skipping.")
+            return
+        cfg = self._vit_config()
+        dtype = getattr(self, "_compute_dtype", torch.bfloat16)
+        gen = torch.Generator(device=self._target_device()).manual_seed(self._seed_for(self.vision_tower_name))
+        logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
+        self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(ViTTrunk.random_canonical(cfg, gen), self._target_device())
+        self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size), height=self._image_size,
+                                                width=self._image_size)
+        self.is_loaded = True
+
+    def _feature_select(self, image_features):
+        if self.select_feature == "patch":
+            return image_features  # the trunk already drops CLS
+        raise ValueError(f"Unexpected select feature: {self.select_feature}")
+
+    def interpolate(self, image_features):
+        """clip_encoder.py:70-96 (also produces the contiguous [B,T,C] copy of the CLS-stripped view)."""
+        target = self._interp_size if self._interp_size is not None else image_features.shape[1]
+        return resample_tokens(image_features, target, force_copy=True)
+
+    def _forward(self, images):
+        with torch.no_grad():  # frozen: clip_encoder.py:103
+            feats = self.vision_tower(images.to(device=self.device))
+            feats = self.interpolate(self._feature_select(feats))
+            return feats.to(images.dtype) if images.dtype in (torch.float32, torch.bfloat16) else feats

@@ -112,9 +112,21 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     else:
         d.workspace, d.workspace_bytes = None, 0
+    prof = GEMM_PROFILE
+    if prof is not None:  # HIP events on the launch stream around this launch (bench.py roofline leg)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = L.load().cmb_gemm(C.byref(d), L.stream_ptr(a.device))
     L.check(rc, f"cmb_gemm(M={M},N={N},K={K},{dt})")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K, dt, split_k))
     return out
+
+
+# bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k) per GEMM launch
+GEMM_PROFILE = None
 
 
 def k_transpose(x: torch.Tensor, r_pad: Optional[int] = None) -> torch.Tensor:
@@ -638,3 +650,74 @@ class RopeFn(torch.autograd.Function):
 
 def rope(x, cos, sin):
     return RopeFn.apply(x, cos, sin)
+
+
+# ================================================================================================
+# autograd: row gather / scatter of the in-LLM SVA hook (cambrian_llama.py:181-207)
+# ================================================================================================
+def k_copy_rows(src: Optional[torch.Tensor], src_map: Optional[RowMap], dst: torch.Tensor, dst_map: RowMap, rows: int,
+                D: int) -> None:
+    L.require_gpu(src, dst)
+    rc = L.load().cmb_copy_rows(L.dtype_code(dst.dtype), L.ptr(src), None if src_map is None else C.byref(src_map),
+                                dst.data_ptr(), C.byref(dst_map), rows, D, L.stream_ptr(dst.device))
+    L.check(rc, "cmb_copy_rows")
+
+
+def hook_row_map(S: int, H: int, side: int) -> RowMap:
+    """query row (b, i, j) -> element offset of hidden[b, i*(side+1)+j, :] relative to hidden[0, image_position]."""
+    return L.make_map(side * side, side, S * H, (side + 1) * H, H)
+
+
+class GatherQueryRowsFn(torch.autograd.Function):
+    """hidden [B,S,H] -> the side*side latent-query rows [B*side*side, H] starting at ``pos`` (newline column
+    skipped): ``hidden[:, pos:pos+side*(side+1)].view(B,side,side+1,H)[:, :, :side]`` as one strided copy."""
+
+    @staticmethod
+    def forward(ctx, hidden, pos: int, side: int):
+        B, S, H = hidden.shape
+        assert hidden.is_contiguous()
+        out = torch.empty((B * side * side, H), dtype=hidden.dtype, device=hidden.device)
+        k_copy_rows(hidden.view(-1)[pos * H:], hook_row_map(S, H, side), out, L.identity_map(H), B * side * side, H)
+        ctx.cfg = (B, S, H, pos, side)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, H, pos, side = ctx.cfg
+        g = g.contiguous()
+        dh = torch.zeros((B, S, H), dtype=g.dtype, device=g.device)
+        k_copy_rows(g, L.identity_map(H), dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)
+        return dh, None, None
+
+
+class ScatterQueryRowsFn(torch.autograd.Function):
+    """In-place write-back of the updated latent queries into ``hidden`` (the reference's
+    ``hidden_states[:, a:b] = latent_query_with_newline``, cambrian_llama.py:207); the newline column and all
+    text rows are untouched."""
+
+    @staticmethod
+    def forward(ctx, hidden, rows, pos: int, side: int):
+        B, S, H = hidden.shape
+        assert hidden.is_contiguous() and rows.is_contiguous()
+        k_copy_rows(rows, L.identity_map(H), hidden.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)
+        ctx.mark_dirty(hidden)
+        ctx.cfg = (B, S, H, pos, side)
+        return hidden
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, H, pos, side = ctx.cfg
+        g = g.contiguous()
+        drows = torch.empty((B * side * side, H), dtype=g.dtype, device=g.device)
+        k_copy_rows(g.view(-1)[pos * H:], hook_row_map(S, H, side), drows, L.identity_map(H), B * side * side, H)
+        dh = g.clone()
+        k_copy_rows(None, None, dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)  # zero the rows
+        return dh, drows, None, None
+
+
+def gather_query_rows(hidden, pos: int, side: int):
+    return GatherQueryRowsFn.apply(hidden, pos, side)
+
+
+def scatter_query_rows(hidden, rows, pos: int, side: int):
+    return ScatterQueryRowsFn.apply(hidden, rows, pos, side)

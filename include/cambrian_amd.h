@@ -238,6 +238,12 @@ int cmb_act_mul(int dtype, int32_t act, const void* a, int64_t lda, const void* 
 /* dx = dy * act'(pre)  (GELU backward for the SVA / projector MLPs). */
 int cmb_act_bwd(int dtype, int32_t act, const void* dy, const void* pre, int64_t n, void* dx,
                 void* stream);
+/* dst[dst_map(r), 0:D] = src[src_map(r), 0:D] for r in [0,rows); src == NULL zero-fills.  Row gather /
+ * scatter of the in-LLM SVA hook: hidden[:, p:p+600].view(B,24,25,H)[:, :, :24] <-> [B*576, H]
+ * (cambrian_llama.py:181-207) and its backward. */
+int cmb_copy_rows(int dtype, const void* src, const cmb_rowmap* src_map, void* dst,
+                  const cmb_rowmap* dst_map, int64_t rows, int64_t D, void* stream);
+
 /* dst[r*ld : r*ld+D] = src[0:D] for r in [0,nrows) — CLS-token rows of the ViT sequence buffers
  * (the position-embedding add itself rides in the patch-embed GEMM epilogue as a row-mapped residual). */
 int cmb_bcast_rows(int dtype, void* dst, int64_t ld, int64_t nrows, int64_t D, const void* src,

@@ -1,0 +1,105 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+CPU fp32 restatement of the LLM-side pieces the north star names:
+  * RMSNorm — the reference's patched ``LlamaRMSNorm.forward`` (train_fsdp.py:1429-1438; same arithmetic as
+    phi3/modeling_phi3.py:83-97): fp32, weight multiplied before the down-cast;
+  * RoPE — phi3/modeling_phi3.py:114-141 (inv_freq, cos/sin in fp32) and :257-281 (rotate_half form);
+  * the in-LLM SVA hook, static branch — cambrian_llama.py:177-207;
+  * fp32 logits + shifted cross-entropy — cambrian_llama.py:402-422;
+  * a plain Llama decoder (HF parameter names) so that whole-model logits can be compared.
+Pinned by tests/golden/llama_small.pt: the reference's own Phi3RMSNorm / Phi3RotaryEmbedding / apply_rotary_pos_emb
+(imported from /root/reference), the hook lines 181-207 exec'd verbatim on seeded tensors, and the installed HF
+``LlamaForCausalLM`` logits for the bare decoder.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import sva as O
+
+IGNORE_INDEX = -100
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    dt = x.dtype
+    h = x.to(torch.float32)
+    h = h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + eps)
+    return (w.to(torch.float32) * h).to(dt)
+
+
+def rope_cos_sin(position_ids: torch.Tensor, dim: int, base: float):
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+    freqs = position_ids[:, :, None].float() * inv_freq[None, None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def rotate_half(x):
+    return torch.cat((-x[..., x.shape[-1] // 2:], x[..., : x.shape[-1] // 2]), dim=-1)
+
+
+def apply_rope(q, k, cos, sin):
+    """q,k [B, heads, S, hd]; cos/sin [B, S, hd]."""
+    cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+    return q * cos + rotate_half(q) * sin, k * cos + rotate_half(k) * sin
+
+
+def sva_hook(hidden: torch.Tensor, sampler_params: Dict[str, torch.Tensor], prefix: str, image_position: int,
+             image_token_len: int, ctx: torch.Tensor, kvs: Sequence[torch.Tensor], masks: Sequence[torch.Tensor]):
+    """cambrian_llama.py:177-207: slice 24x25 rows, drop the newline column, run the sampler, write back."""
+    side = int(image_token_len ** 0.5)
+    n_nl = image_token_len + side
+    blk = hidden[:, image_position:image_position + n_nl, :].clone()
+    bs = blk.shape[0]
+    blk = blk.view(bs, side, side + 1, -1)
+    q, nl = blk[:, :, :-1, :], blk[:, :, -1:, :]
+    q = q.reshape(bs * image_token_len, 1, -1)
+    q = O.vision_token_sampler(sampler_params, q, ctx, [k.to(q.dtype) for k in kvs], masks, prefix=prefix)
+    q = q.view(bs, side, side, -1)
+    out = hidden.clone()
+    out[:, image_position:image_position + n_nl] = torch.cat([q, nl], 2).flatten(1, 2)
+    return out
+
+
+def decoder_forward(p: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor, position_ids: torch.Tensor,
+                    attention_mask: Optional[torch.Tensor] = None, hook=None) -> torch.Tensor:
+    """Plain Llama decoder with HF key names (model.layers.{i}....); ``hook(i, hidden)`` runs after layer i."""
+    B, S, H = inputs_embeds.shape
+    nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
+    hd = H // nh
+    cos, sin = rope_cos_sin(position_ids, hd, cfg.rope_theta)
+    causal = torch.ones(S, S, dtype=torch.bool).tril_()
+    mask = causal[None, None]
+    if attention_mask is not None:
+        mask = (mask & attention_mask.bool()[:, None, None, :]) | torch.eye(S, dtype=torch.bool)[None, None]
+    x = inputs_embeds
+    for i in range(cfg.num_hidden_layers):
+        pre = f"model.layers.{i}."
+        h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg.rms_norm_eps)
+        q = (h @ p[pre + "self_attn.q_proj.weight"].T).view(B, S, nh, hd).transpose(1, 2)
+        k = (h @ p[pre + "self_attn.k_proj.weight"].T).view(B, S, nkv, hd).transpose(1, 2)
+        v = (h @ p[pre + "self_attn.v_proj.weight"].T).view(B, S, nkv, hd).transpose(1, 2)
+        q, k = apply_rope(q, k, cos, sin)
+        k = k.repeat_interleave(nh // nkv, dim=1)
+        v = v.repeat_interleave(nh // nkv, dim=1)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        s = s.masked_fill(~mask, float("-inf"))
+        a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, H)
+        x = x + a @ p[pre + "self_attn.o_proj.weight"].T
+        h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+        x = x + (F.silu(h @ p[pre + "mlp.gate_proj.weight"].T) * (h @ p[pre + "mlp.up_proj.weight"].T)) @ p[pre + "mlp.down_proj.weight"].T
+        if hook is not None:
+            x = hook(i, x)
+    return rms_norm(x, p["model.norm.weight"], cfg.rms_norm_eps)
+
+
+def lm_loss(hidden: torch.Tensor, lm_head: torch.Tensor, labels: torch.Tensor):
+    """cambrian_llama.py:402-422."""
+    logits = (hidden @ lm_head.T).float()
+    shift_logits = logits[..., :-1, :].contiguous().view(-1, logits.shape[-1])
+    shift_labels = labels[..., 1:].contiguous().view(-1)
+    return F.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX), logits

@@ -94,6 +94,277 @@ def golden_sva():
     print("sva_small.pt", sum(v.numel() for v in fx["state"].values()), "params")
 
 
+def golden_towers():
+    """Outputs of the installed HF modules (the third-party arithmetic the reference delegates to) on seeded
+    small configs; replayed through oracle/towers.py via cambrian_amd/.../weight_maps.py."""
+    from transformers import (CLIPVisionConfig, CLIPVisionModel, ConvNextConfig, ConvNextModel, Dinov2Config,
+                              Dinov2Model, SiglipVisionConfig, SiglipVisionModel)
+    torch.manual_seed(4321)
+    fx = {}
+
+    def perturb(m):
+        with torch.no_grad():
+            for n, p_ in m.named_parameters():
+                if p_.dim() == 1:
+                    p_.add_(0.1 * torch.randn_like(p_))
+                elif "position" in n or "cls" in n or "class" in n:
+                    p_.add_(0.1 * torch.randn_like(p_))
+
+    img = torch.randn(2, 3, 28, 28)
+    m = CLIPVisionModel(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3,
+                                         num_attention_heads=4, image_size=28, patch_size=14, hidden_act="quick_gelu",
+                                         layer_norm_eps=1e-5)).eval()
+    perturb(m)
+    with torch.no_grad():
+        hs = m(img, output_hidden_states=True).hidden_states
+    fx["clip"] = dict(sd=m.state_dict(), img=img, out=hs[-2][:, 1:].clone(), n_hidden=len(hs))
+    m = Dinov2Model(Dinov2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, image_size=28,
+                                 patch_size=14, use_swiglu_ffn=True, mlp_ratio=4, layer_norm_eps=1e-6,
+                                 layerscale_value=0.5)).eval()
+    perturb(m)
+    with torch.no_grad():
+        out = m(img).last_hidden_state[:, 1:].clone()
+    fx["dino_swiglu"] = dict(sd=m.state_dict(), img=img, out=out)
+    m = Dinov2Model(Dinov2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, image_size=28,
+                                 patch_size=14, use_swiglu_ffn=False, mlp_ratio=2, layer_norm_eps=1e-6)).eval()
+    perturb(m)
+    with torch.no_grad():
+        out = m(img).last_hidden_state[:, 1:].clone()
+    fx["dino_mlp"] = dict(sd=m.state_dict(), img=img, out=out)
+    m = SiglipVisionModel(SiglipVisionConfig(hidden_size=64, intermediate_size=144, num_hidden_layers=2,
+                                             num_attention_heads=4, image_size=28, patch_size=14,
+                                             hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6)).eval()
+    perturb(m)
+    with torch.no_grad():
+        out = m(img).last_hidden_state.clone()
+    fx["siglip"] = dict(sd={k: v for k, v in m.state_dict().items() if "head." not in k}, img=img, out=out)
+    img2 = torch.randn(2, 3, 64, 64)
+    m = ConvNextModel(ConvNextConfig(num_channels=3, hidden_sizes=[16, 32, 64, 128], depths=[1, 1, 2, 1],
+                                     layer_scale_init_value=0.5)).eval()
+    perturb(m)
+    with torch.no_grad():
+        hs = m(img2, output_hidden_states=True).hidden_states
+    fx["convnext"] = dict(sd=m.state_dict(), img=img2, stages=[h.clone() for h in hs[1:]], depths=[1, 1, 2, 1],
+                          dims=[16, 32, 64, 128])
+    torch.save(fx, f"{OUT}/towers_small.pt")
+    print("towers_small.pt written")
+
+
+def golden_collator():
+    """The reference's own get_padding_offset / prepare_image_info / prepare_multimodal_data on a set of cases
+    (square, wide, tall, extreme aspect, image token at several positions, padded rows)."""
+    ns = load_ref_collator()
+    g = torch.Generator().manual_seed(99)
+    cases = []
+    for (image_token_len, aux_lens, max_len, sizes, positions) in [
+        (576, [576, 576, 576, 9216], 2048, [(336, 336), (336, 224), (200, 640), (1000, 90)], [91, 35, 0, 1300]),
+        (144, [144, 576, 2304], 512, [(100, 100), (640, 480), (90, 1000)], [5, 87, 200]),
+        (16, [16, 64], 64, [(3, 2), (2, 3)], [0, 20]),
+    ]:
+        B = len(sizes)
+        ids = torch.randint(1000, 30000, (B, max_len), generator=g)
+        labels = ids.clone()
+        att = torch.ones(B, max_len, dtype=torch.bool)
+        for b, p in enumerate(positions):
+            ids[b, p] = -200
+            labels[b, :p + 1] = -100
+        att[B - 1, max_len // 2:] = False   # a padded tail on the last row
+        out = ns["prepare_multimodal_data"](ids.clone(), labels.clone(), att.clone(), sizes, image_token_len, aux_lens, max_len)
+        cases.append(dict(image_token_len=image_token_len, aux_lens=aux_lens, max_len=max_len, sizes=sizes, ids=ids,
+                          labels=labels, att=att, out_ids=out[0], out_labels=out[1], out_att=out[2], out_pos=out[3],
+                          out_aux=out[4]))
+    offs = {}
+    for cur in [(24, 24), (96, 96), (12, 12), (4, 4)]:
+        for orig in [(336, 336), (336, 224), (224, 336), (1000, 90), (90, 1000), (3, 2), (641, 479)]:
+            offs[(cur, orig)] = ns["get_padding_offset"](cur, orig)
+    info = {}
+    for size in [(336, 336), (336, 224), (224, 336), (1000, 90)]:
+        for tl in [576, 9216, 16]:
+            for nl in [False, True]:
+                m, p = ns["prepare_image_info"](size, tl, newline=nl)
+                info[(size, tl, nl)] = (m, p)
+    torch.save(dict(cases=cases, offsets=offs, info=info), f"{OUT}/collator_cases.pt")
+    print("collator_cases.pt written")
+
+
+def golden_arch():
+    """The real CambrianMetaForCausalLM.prepare_inputs_labels_for_multimodal (static branch) with fake towers."""
+    import torch.nn as nn
+    A = load_ref_arch()
+    ns = load_ref_collator()
+    torch.manual_seed(777)
+    H, vh, side, B, S, V = 96, 64, 4, 2, 64, 50
+    tower_dims, token_lens = [48, 80], [16, 64]
+
+    class FakeTower(nn.Module):
+        def __init__(self, hidden, tokens):
+            super().__init__()
+            self.hidden_size, self.tokens, self.is_loaded = hidden, tokens, True
+            self.out = None
+
+        def load_model(self):
+            pass
+
+        def forward(self, images):
+            return self.out
+
+    towers = [FakeTower(d, t) for d, t in zip(tower_dims, token_lens)]
+
+    class Cfg:
+        pass
+
+    cfg = Cfg()
+    cfg.hidden_size, cfg.vision_hidden_size = H, vh
+    cfg.mm_vision_tower_aux_list = ["a", "b"]
+    cfg.mm_vision_tower_aux_token_len_list = token_lens
+    cfg.mm_projector_type = "sva"
+    cfg.num_query_group, cfg.query_num_list, cfg.connector_only, cfg.connector_depth = 1, [side * side], False, 2
+    cfg.image_token_len = side * side
+    cfg.num_of_vision_sampler_layers, cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers = 2, 0, 1
+    cfg._fake_towers = towers
+
+    class Base(nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+            self.embed_tokens = nn.Embedding(V, H)
+
+        @property
+        def dtype(self):
+            return torch.float32
+
+    class Model(A.CambrianMetaModel, Base):
+        pass
+
+    class LM(nn.Module, A.CambrianMetaForCausalLM):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.model = Model(cfg)
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    lm = LM()
+    with torch.no_grad():
+        lm.model.image_newline.copy_(torch.randn(H) / H ** 0.5)
+        lm.model.vision_query.mul_(1 / vh ** 0.5)
+        for n, p_ in lm.named_parameters():
+            if p_.dim() == 1 and "newline" not in n:
+                p_.add_(0.1 * torch.randn_like(p_))
+    ids = torch.randint(1, V, (B, 40))
+    labels = ids.clone()
+    att = torch.ones(B, 40, dtype=torch.bool)
+    ids[0, 5] = -200
+    ids[1, 17] = -200
+    sizes = [(336, 336), (336, 150)]
+    new_ids, new_lab, new_att, new_pos, aux_masks = ns["prepare_multimodal_data"](ids, labels, att, sizes, side * side,
+                                                                               token_lens, S)
+    feats = [torch.randn(B, t, d, requires_grad=True) for t, d in zip(token_lens, tower_dims)]
+    for t, f in zip(towers, feats):
+        t.out = f
+    images = [torch.zeros(B, 3, 8, 8) for _ in towers]
+    out = lm.prepare_inputs_labels_for_multimodal(new_ids, new_pos, new_att, None, new_lab, images, aux_masks, sizes)
+    emb = out[4]
+    w = torch.randn_like(emb)
+    (emb * w).sum().backward()
+    fx = dict(cfg=dict(H=H, vh=vh, side=side, B=B, S=S, V=V, tower_dims=tower_dims, token_lens=token_lens,
+                       connector_depth=2, n_in_llm=2),
+              state={k: v.detach().clone() for k, v in lm.model.state_dict().items()},
+              ids=new_ids, pos=new_pos, att=new_att, labels=new_lab, aux_masks=aux_masks, sizes=sizes,
+              feats=[f.detach().clone() for f in feats], embeds=emb.detach().clone(),
+              kv_final=[t.detach().clone() for t in out[6]], mask_final=[t.clone() for t in out[7]],
+              final_size=out[8], ctx_final=out[9].detach().clone(), w=w,
+              dfeats=[f.grad.clone() for f in feats],
+              dparams={n: p_.grad.clone() for n, p_ in lm.model.named_parameters() if p_.grad is not None})
+    torch.save(fx, f"{OUT}/arch_small.pt")
+    print("arch_small.pt written:", sorted(fx["dparams"].keys())[:4], "...")
+
+
+def golden_llama():
+    """(a) the reference's vendored Phi3RMSNorm / rotary embedding / apply_rotary_pos_emb
+    (phi3/modeling_phi3.py:83-97,114-141,257-281) on seeded tensors; (b) the in-LLM SVA hook, static branch:
+    cambrian_llama.py lines 181-207 exec'd verbatim with the reference VisionTokenSampler; (c) logits of the
+    installed HF LlamaForCausalLM (tiny config) for the bare decoder arithmetic."""
+    import textwrap
+    load_ref_arch()  # registers the stub packages so the phi3 module can be imported by path
+    spec = importlib.util.spec_from_file_location(
+        "cambrian.model.language_model.phi3.modeling_phi3",
+        f"{REF}/cambrian/model/language_model/phi3/modeling_phi3.py")
+    for name, path in [("cambrian.model.language_model.phi3", f"{REF}/cambrian/model/language_model/phi3")]:
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+    phi3 = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = phi3
+    spec.loader.exec_module(phi3)
+    torch.manual_seed(2024)
+    fx = {}
+    x = torch.randn(3, 10, 96)
+    norm = phi3.Phi3RMSNorm(96, eps=1e-5)
+    with torch.no_grad():
+        norm.weight.add_(0.1 * torch.randn(96))
+    fx["rms"] = dict(x=x, w=norm.weight.detach().clone(), eps=1e-5, out=norm(x).detach())
+    rot = phi3.Phi3RotaryEmbedding(32, max_position_embeddings=4096, base=500000.0)
+    pos = torch.randint(0, 3000, (2, 12))
+    q, k = torch.randn(2, 4, 12, 32), torch.randn(2, 2, 12, 32)
+    cos, sin = rot(q, pos, seq_len=None)
+    qe, ke = phi3.apply_rotary_pos_emb(q, k, cos, sin, pos)
+    fx["rope"] = dict(pos=pos, q=q, k=k, base=500000.0, cos=cos, sin=sin, q_out=qe, k_out=ke)
+
+    # (b) hook: exec the reference lines verbatim
+    vs = load_ref_vision_sampler()
+    H, vh, side, B, S, p0 = 96, 64, 4, 2, 40, 7
+    sampler = vs.VisionTokenSampler(H, vh, [vh, vh], [1, 2], vh, 1).float()
+    src = open(f"{REF}/cambrian/model/language_model/cambrian_llama.py").read().split("\n")
+    body = textwrap.dedent("\n".join(src[176:207]))  # lines 177-207: the IS_XLA_AVAILABLE branch body
+    # :187 `latent_query.view(bs*latent_query_num, 1, -1)` is applied to a non-contiguous slice: legal on XLA
+    # (functional views), a RuntimeError on eager CPU/GPU torch.  Same values with reshape.
+    assert "latent_query = latent_query.view(bs*latent_query_num, 1, -1)" in body
+    body = body.replace("latent_query = latent_query.view(bs*latent_query_num, 1, -1)",
+                        "latent_query = latent_query.reshape(bs*latent_query_num, 1, -1)")
+
+    class Self:
+        pass
+
+    me = Self()
+    me.config = types.SimpleNamespace(image_token_len=side * side, image_position=p0)
+    me.gradient_checkpointing, me.training = False, False
+    me.vision_sampler_layers = [sampler]
+    hidden = torch.randn(B, S, H)
+    kvs = [torch.randn(B * side * side, s * s, vh) for s in (1, 2)]
+    masks = [torch.ones(B * side * side, s * s, dtype=torch.bool) for s in (1, 2)]
+    masks[1][3, :2] = False
+    ctx = torch.randn(B * side * side, 1, vh)
+    ns = dict(self=me, torch=torch, hidden_states=hidden.clone(), latent_query_start_idx=p0,
+              vision_tower_aux_feature_list=kvs, vision_tower_aux_attention_masks_list=masks,
+              global_context_feature=ctx, i=0, cross_layers_start_idx=0, cross_index_step=1, IS_XLA_AVAILABLE=True)
+    with torch.no_grad():
+        exec(body, ns)
+    fx["hook"] = dict(cfg=dict(H=H, vh=vh, side=side, B=B, S=S, p0=p0), state={k: v.detach().clone() for k, v in sampler.state_dict().items()},
+                      hidden=hidden, kvs=kvs, masks=masks, ctx=ctx, out=ns["hidden_states"].detach().clone())
+
+    # (c) bare decoder
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(vocab_size=101, hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=500000.0, max_position_embeddings=128,
+                      attn_implementation="eager")
+    lm = LlamaForCausalLM(cfg).eval()
+    ids = torch.randint(0, 101, (2, 24))
+    pos = torch.arange(24)[None].expand(2, -1)
+    with torch.no_grad():
+        logits = lm(input_ids=ids, position_ids=pos).logits
+    fx["decoder"] = dict(state={k: v.detach().clone() for k, v in lm.state_dict().items()}, ids=ids, pos=pos, logits=logits,
+                         cfg=dict(hidden_size=64, intermediate_size=160, num_hidden_layers=2, num_attention_heads=4,
+                                  num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=500000.0, vocab_size=101))
+    torch.save(fx, f"{OUT}/llama_small.pt")
+    print("llama_small.pt written")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sva"]
     for w in which:

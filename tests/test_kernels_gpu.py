@@ -397,7 +397,8 @@ def test_act_kernels(dev, name, dt):
     assert rel_err(out, ref) < TOL[name]
     pre = h.float().clone().requires_grad_()
     F.gelu(pre).backward(torch.ones_like(pre))
-    dx = torch.empty_like(h, device=dev)
-    rc = L.load().cmb_act_bwd(L.dtype_code(dt), L.ACT_GELU_ERF, torch.ones_like(h, device=dev).data_ptr(),
-                              h.to(dev).data_ptr(), h.numel(), dx.data_ptr(), L.stream_ptr(dev))
+    hd, ones = h.to(dev), torch.ones_like(h, device=dev)  # keep the device buffers alive across the raw call
+    dx = torch.empty_like(hd)
+    rc = L.load().cmb_act_bwd(L.dtype_code(dt), L.ACT_GELU_ERF, ones.data_ptr(), hd.data_ptr(), hd.numel(),
+                              dx.data_ptr(), L.stream_ptr(dev))
     assert rc == 0 and rel_err(dx, pre.grad) < TOL[name]

@@ -1,0 +1,161 @@
+"""`-m gpu`: whole hot path, end to end — towers -> aux projectors -> SVA connector -> mm_projector -> newline +
+splice -> decoder with the in-LLM SVA hook -> fp32 logits + loss, forward AND backward — HIP path vs the composed
+CPU oracle (oracle/{towers,arch,llama}.py, each pinned to the reference by tests/golden/*.pt) on a small config.
+
+Stated tolerance (BASELINE.json north_star: "logits within 1e-3 rel of reference"): rel = max|a-b| / max|b|.
+fp32 mode (exact-fp32 MFMA / VALU kernels): logits rel <= 1e-3 (observed ~1e-5).  bf16 mode (production dtype,
+bf16 storage / fp32 accumulate, same as the reference's own bf16 compute): logits rel <= 5e-2 vs the fp32 oracle.
+"""
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+SIDE, S, P0, VH = 4, 64, 5, 1024
+
+
+class _SmallTower(nn.Module):
+    """Protocol-compatible stand-in with a small native trunk (the real ones are 0.3-1.1 B parameters)."""
+
+    def __init__(self, kind, dev, dt, seed):
+        super().__init__()
+        from cambrian_amd.model.multimodal_encoder.convnext import ConvNeXtConfig, ConvNeXtTrunk
+        from cambrian_amd.model.multimodal_encoder.vit import ViTConfig, ViTTrunk
+        gen = torch.Generator().manual_seed(seed)
+        self.kind = kind
+        if kind == "vit":   # 56 px / 14 -> 4x4 = 16 tokens
+            self.cfg = ViTConfig(image_size=56, patch_size=14, hidden_size=128, num_layers=2, num_heads=2, mlp_dim=256,
+                                 act="gelu", ln_eps=1e-6, has_cls=True, final_ln=True)
+            self.canon = ViTTrunk.random_canonical(self.cfg, gen)
+            self.trunk = ViTTrunk(self.cfg, dt).load_canonical(self.canon, dev)
+            self.hidden_size, self.res, self.tokens = 128, 56, 16
+        else:               # 64 px -> stages 16/8/4/2 -> each resampled to 8x8 = 64 tokens, 64+128 channels... (4 stages)
+            self.cfg = ConvNeXtConfig(depths=(1, 1, 1, 1), dims=(64, 64, 128, 128), ln_eps=1e-5)
+            self.canon = ConvNeXtTrunk.random_canonical(self.cfg, gen)
+            self.trunk = ConvNeXtTrunk(self.cfg, dt).load_canonical(self.canon, dev)
+            self.hidden_size, self.res, self.tokens = 384, 64, 64
+        self.is_loaded = True
+
+    def load_model(self, device_map=None):
+        pass
+
+    def forward(self, images):
+        if self.kind == "vit":
+            from cambrian_amd.model.multimodal_encoder.vit import resample_tokens
+            return resample_tokens(self.trunk(images), self.tokens, force_copy=True)
+        return self.trunk(images, 8, multi_stage=True)
+
+    def oracle(self, images):
+        from oracle import towers as O
+        if self.kind == "vit":
+            return O.vit_forward(self.cfg, self.canon, images)
+        return O.convnext_forward(self.cfg, self.canon, images, 8, multi_stage=True)
+
+
+def _build(dev, dt, monkeypatch):
+    from cambrian_amd.model import cambrian_arch
+    from cambrian_amd.model.language_model import cambrian_llama as CL
+    towers = [_SmallTower("vit", dev, dt, 1), _SmallTower("convnext", dev, dt, 2)]
+    import cambrian_amd.model.cambrian_arch as A
+    monkeypatch.setattr(A, "build_vision_tower_aux_list", lambda cfg, **kw: towers)
+    cfg = CL.CambrianConfig(vocab_size=300, hidden_size=256, intermediate_size=512, num_hidden_layers=4,
+                            num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=500000.0,
+                            max_position_embeddings=256)
+    CL.apply_release_8b_vision_config(cfg, towers=["t0", "t1"], token_lens=[16, 64])
+    cfg.image_token_len, cfg.query_num_list, cfg.connector_depth = SIDE * SIDE, [SIDE * SIDE], 2
+    cfg.num_of_vision_sampler_layers, cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers = 2, 0, 2
+    cfg.image_position, cfg.vision_hidden_size = P0, VH
+    torch.manual_seed(0)
+    model = CL.CambrianLlamaForCausalLM(cfg, device=dev, llm_dtype=dt)
+    with torch.no_grad():
+        model.model.image_newline.copy_(torch.randn(256) / 16)
+        model.model.vision_query.mul_(1 / 32)
+        for n, p in model.named_parameters():
+            if p.dim() == 1 and "newline" not in n:
+                p.add_(0.1 * torch.randn_like(p))
+            if "pos_embed" in n:
+                p.mul_(0.5)
+    model = model.to(dev)
+    # pre-training stage: only the connector trains (train_fsdp.py:1677-1685)
+    keys = ("mm_projector", "pos_emb", "vision_sampler", "vision_sampler_layers", "vision_query", "image_newline")
+    for n, p in model.named_parameters():
+        p.requires_grad_(any(k in n for k in keys))
+    return model, cfg, towers
+
+
+def _oracle_run(model, cfg, towers, batch):
+    from oracle import arch as OA, llama as OL
+    p = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    train_names = {n for n, q in model.named_parameters() if q.requires_grad}
+    for k in list(p):
+        if k in train_names:
+            p[k].requires_grad_()
+    pm = {k[len("model."):]: v for k, v in p.items() if k.startswith("model.")}
+    feats = [t.oracle(img) for t, img in zip(towers, batch["images"])]
+    emb, kv_final, mask_final, ctx_final = OA.prepare_inputs_static(pm, cfg, batch["input_ids"], feats,
+                                                                    batch["image_aux_attention_masks_list"],
+                                                                    pm["embed_tokens.weight"])
+    start, stride = cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers
+    hooks = {start + k * stride: k for k in range(cfg.num_of_vision_sampler_layers)}
+
+    def hook(i, x):
+        if i not in hooks:
+            return x
+        return OL.sva_hook(x, pm, f"vision_sampler_layers.{hooks[i]}.", cfg.image_position, cfg.image_token_len, ctx_final,
+                           kv_final, mask_final)
+
+    hidden = OL.decoder_forward(p, cfg, emb, batch["position_ids"], batch["attention_mask"], hook)
+    loss, logits = OL.lm_loss(hidden, p["lm_head.weight"], batch["labels"])
+    return loss, logits, p
+
+
+@pytest.mark.parametrize("name,dt,tol_logits,tol_grad", [("fp32", torch.float32, 1e-3, 5e-3),
+                                                          ("bf16", torch.bfloat16, 5e-2, 1.5e-1)])
+def test_end_to_end_logits_loss_and_gradients(dev, monkeypatch, name, dt, tol_logits, tol_grad):
+    from cambrian_amd.train.data_layout import synthetic_batch
+    model, cfg, towers = _build(dev, dt, monkeypatch)
+    batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
+                            image_res=[56, 64], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
+    ref_loss, ref_logits, p = _oracle_run(model, cfg, towers, batch)
+    ref_loss.backward()
+
+    out = model(input_ids=batch["input_ids"].to(dev), attention_mask=batch["attention_mask"].to(dev),
+                position_ids=batch["position_ids"].to(dev), labels=batch["labels"].to(dev),
+                images=[i.to(dev, dt) for i in batch["images"]],
+                image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
+                image_sizes=batch["image_sizes"])
+    out.loss.backward()
+    e = rel_err(out.logits, ref_logits)
+    assert e < tol_logits, f"logits rel err {e}"
+    assert abs(out.loss.item() - ref_loss.item()) < tol_logits * max(1.0, abs(ref_loss.item()))
+    worst = ("", 0.0)
+    n_checked = 0
+    for n, q in model.named_parameters():
+        if not q.requires_grad:
+            assert q.grad is None
+            continue
+        assert q.grad is not None, n
+        g_ref = p[n].grad
+        if g_ref is None or g_ref.abs().max() == 0:
+            continue
+        err = rel_err(q.grad, g_ref)
+        n_checked += 1
+        if err > worst[1]:
+            worst = (n, err)
+    assert n_checked > 50
+    assert worst[1] < tol_grad, f"worst trainable-parameter gradient {worst}"
+
+
+def test_text_only_early_out(dev, monkeypatch):
+    """cambrian_arch.py:346-347: no images -> inputs returned untouched, plain LM forward."""
+    model, cfg, towers = _build(dev, torch.float32, monkeypatch)
+    ids = torch.randint(1, 300, (2, 16), device=dev)
+    r = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, None)
+    assert r[0] is ids and r[4] is None and r[6] is None and len(r) == 10
+    out = model(input_ids=ids, labels=ids)
+    assert out.logits.shape == (2, 16, 300) and torch.isfinite(out.loss)

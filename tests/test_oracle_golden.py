@@ -39,3 +39,155 @@ def test_sva_oracle_mask_size_check():
     bad[2] = bad[2][:, :3]
     with pytest.raises(ValueError, match="Attention mask should be of size"):
         sva.vision_token_sampler(fx["state"], fx["q"], fx["ctx"], fx["kvs"], bad)
+
+
+# ------------------------------------------------------------------------------------------------ towers
+def _vit_cfg(**kw):
+    from cambrian_amd.model.multimodal_encoder.vit import ViTConfig
+    return ViTConfig(**kw)
+
+
+def test_tower_oracle_matches_hf_clip():
+    from oracle import towers
+    from cambrian_amd.model.multimodal_encoder import weight_maps as W
+    fx = _load("towers_small.pt")["clip"]
+    cfg = _vit_cfg(image_size=28, patch_size=14, hidden_size=64, num_layers=3, num_heads=4, mlp_dim=128, act="quick_gelu",
+                   ln_eps=1e-5, has_cls=True, pre_ln=True, final_ln=False, patch_bias=False, run_layers=3 + 1 - 2)
+    out = towers.vit_forward(cfg, W.hf_clip_to_canonical(fx["sd"], 3), fx["img"])  # hidden_states[-2], CLS dropped
+    assert torch.allclose(out, fx["out"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("key,swiglu,mlp_dim", [("dino_swiglu", True, 176), ("dino_mlp", False, 128)])
+def test_tower_oracle_matches_hf_dinov2(key, swiglu, mlp_dim):
+    from oracle import towers
+    from cambrian_amd.model.multimodal_encoder import weight_maps as W
+    fx = _load("towers_small.pt")[key]
+    cfg = _vit_cfg(image_size=28, patch_size=14, hidden_size=64, num_layers=2, num_heads=4, mlp_dim=mlp_dim,
+                   act="swiglu" if swiglu else "gelu", ln_eps=1e-6, has_cls=True, final_ln=True, layerscale=True)
+    out = towers.vit_forward(cfg, W.hf_dinov2_to_canonical(fx["sd"], 2, swiglu), fx["img"])
+    assert torch.allclose(out, fx["out"], atol=2e-5, rtol=1e-4)
+
+
+def test_tower_oracle_matches_hf_siglip():
+    from oracle import towers
+    from cambrian_amd.model.multimodal_encoder import weight_maps as W
+    fx = _load("towers_small.pt")["siglip"]
+    cfg = _vit_cfg(image_size=28, patch_size=14, hidden_size=64, num_layers=2, num_heads=4, mlp_dim=144, act="gelu_tanh",
+                   ln_eps=1e-6, has_cls=False, final_ln=True)
+    out = towers.vit_forward(cfg, W.hf_siglip_to_canonical(fx["sd"], 2), fx["img"])
+    assert torch.allclose(out, fx["out"], atol=2e-5, rtol=1e-4)
+
+
+def test_tower_oracle_matches_hf_convnext():
+    from oracle import towers
+    from cambrian_amd.model.multimodal_encoder import weight_maps as W
+    from cambrian_amd.model.multimodal_encoder.convnext import ConvNeXtConfig
+    fx = _load("towers_small.pt")["convnext"]
+    cfg = ConvNeXtConfig(depths=fx["depths"], dims=fx["dims"], ln_eps=1e-6)
+    stages = towers.convnext_stages(cfg, W.hf_convnext_to_canonical(fx["sd"], fx["depths"]), fx["img"])
+    for a, b in zip(stages, fx["stages"]):
+        assert torch.allclose(a, b, atol=5e-5, rtol=1e-4)
+
+
+def test_dinov2_pos_interpolation_follows_the_4_37_pin():
+    """transformers==4.37.0 Dinov2Embeddings.interpolate_pos_encoding: bicubic with scale_factor=(g+0.1)/sqrt(N)."""
+    import torch.nn.functional as F
+    from cambrian_amd.model.multimodal_encoder.dino_encoder import interpolate_pos_encoding
+    g = torch.Generator().manual_seed(0)
+    pos = torch.randn(1 + 37 * 37, 32, generator=g)
+    out = interpolate_pos_encoding(pos, 27)
+    assert out.shape == (1 + 27 * 27, 32) and torch.equal(out[0], pos[0])
+    ref = F.interpolate(pos[1:].reshape(1, 37, 37, 32).permute(0, 3, 1, 2), scale_factor=(27.1 / 37, 27.1 / 37),
+                        mode="bicubic", align_corners=False).permute(0, 2, 3, 1).reshape(-1, 32)
+    assert torch.allclose(out[1:], ref, atol=1e-6)
+    assert torch.equal(interpolate_pos_encoding(pos, 37), pos)
+
+
+# ------------------------------------------------------------------------------------------- glue / collator
+def test_collator_oracle_bit_exact_vs_reference():
+    """train_fsdp.py:1039-1165 — INT/bool arithmetic: bit-exact."""
+    from oracle import arch
+    fx = _load("collator_cases.pt")
+    for (cur, orig), want in fx["offsets"].items():
+        assert arch.get_padding_offset(cur, orig) == tuple(want)
+    for (size, tl, nl), (m, p) in fx["info"].items():
+        gm, gp = arch.prepare_image_info(size, tl, newline=nl)
+        assert torch.equal(gm, m) and torch.equal(gp, p)
+    for c in fx["cases"]:
+        ids, lab, att, pos, aux = arch.prepare_multimodal_data(c["ids"], c["labels"], c["att"], c["sizes"],
+                                                               c["image_token_len"], c["aux_lens"], c["max_len"])
+        assert torch.equal(ids, c["out_ids"]) and torch.equal(lab, c["out_labels"])
+        assert torch.equal(att, c["out_att"]) and torch.equal(pos, c["out_pos"])
+        assert len(aux) == len(c["out_aux"])
+        for a, b in zip(aux, c["out_aux"]):
+            assert a.dtype == torch.bool and torch.equal(a, b)
+
+
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def test_arch_oracle_matches_reference_prepare_inputs():
+    """cambrian_arch.py:340-490 static branch, forward and gradients, plus the bit-exact window gather (:271-287)."""
+    from oracle import arch
+    fx = _load("arch_small.pt")
+    c = fx["cfg"]
+    cfg = _NS(image_token_len=c["side"] ** 2, query_num_list=[c["side"] ** 2])
+    p = {k: v.clone().requires_grad_() for k, v in fx["state"].items()}
+    feats = [f.clone().requires_grad_() for f in fx["feats"]]
+    emb, kv_final, mask_final, ctx_final = arch.prepare_inputs_static(p, cfg, fx["ids"], feats, fx["aux_masks"],
+                                                                      p["embed_tokens.weight"])
+    assert torch.allclose(emb, fx["embeds"], atol=2e-6, rtol=1e-5)
+    for a, b in zip(kv_final, fx["kv_final"]):
+        assert torch.allclose(a, b, atol=2e-6, rtol=1e-5)
+    for a, b in zip(mask_final, fx["mask_final"]):
+        assert torch.equal(a, b)
+    assert torch.allclose(ctx_final, fx["ctx_final"], atol=2e-6, rtol=1e-5)
+    (emb * fx["w"]).sum().backward()
+    for a, b in zip(feats, fx["dfeats"]):
+        assert torch.allclose(a.grad, b, atol=1e-5, rtol=1e-4)
+    for name, g in fx["dparams"].items():
+        if name == "embed_tokens.weight":
+            continue
+        assert torch.allclose(p[name].grad, g, atol=2e-5, rtol=1e-4), name
+    # text rows / visual rows are pure copies
+    pos0 = int((fx["ids"][0] == -200).nonzero()[0])
+    assert torch.equal(emb[0, :pos0], p["embed_tokens.weight"][fx["ids"][0, :pos0]])
+
+
+# ------------------------------------------------------------------------------------------------ LLM side
+def test_rmsnorm_rope_oracle_match_reference_phi3():
+    """phi3/modeling_phi3.py:83-97 (RMSNorm), :114-141 + :257-281 (RoPE) — the reference's own classes."""
+    from oracle import llama
+    fx = _load("llama_small.pt")
+    r = fx["rms"]
+    assert torch.allclose(llama.rms_norm(r["x"], r["w"], r["eps"]), r["out"], atol=1e-6, rtol=1e-6)
+    t = fx["rope"]
+    cos, sin = llama.rope_cos_sin(t["pos"], 32, t["base"])
+    assert torch.allclose(cos, t["cos"], atol=1e-6) and torch.allclose(sin, t["sin"], atol=1e-6)
+    q, k = llama.apply_rope(t["q"], t["k"], cos, sin)
+    assert torch.allclose(q, t["q_out"], atol=1e-6) and torch.allclose(k, t["k_out"], atol=1e-6)
+
+
+def test_hook_oracle_matches_reference_lines():
+    """cambrian_llama.py:177-207 exec'd verbatim (tests/golden/make_golden.py) vs oracle.llama.sva_hook."""
+    from oracle import llama
+    fx = _load("llama_small.pt")["hook"]
+    c = fx["cfg"]
+    out = llama.sva_hook(fx["hidden"], fx["state"], "", c["p0"], c["side"] ** 2, fx["ctx"], fx["kvs"], fx["masks"])
+    assert torch.allclose(out, fx["out"], atol=2e-6, rtol=1e-5)
+    keep = torch.ones(c["S"], dtype=torch.bool)
+    keep[c["p0"]:c["p0"] + c["side"] * (c["side"] + 1)].view(c["side"], c["side"] + 1)[:, :c["side"]] = False
+    assert torch.equal(out[:, keep], fx["hidden"][:, keep])  # text rows and the newline column untouched
+
+
+def test_decoder_oracle_matches_hf_llama():
+    from oracle import llama
+    fx = _load("llama_small.pt")["decoder"]
+    cfg = _NS(**fx["cfg"])
+    p = fx["state"]
+    emb = p["model.embed_tokens.weight"][fx["ids"]]
+    hidden = llama.decoder_forward(p, cfg, emb, fx["pos"])
+    _, logits = llama.lm_loss(hidden, p["lm_head.weight"], fx["ids"])
+    assert torch.allclose(logits, fx["logits"], atol=2e-5, rtol=1e-4)
