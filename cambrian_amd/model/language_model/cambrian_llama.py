@@ -37,6 +37,13 @@ class CambrianConfig(LlamaConfig):
     model_type = "cambrian_llama"
     debug = "debug"
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # transformers 5.x folds rope_theta into `rope_parameters`; keep the 4.37 attribute the reference reads
+        if not hasattr(self, "rope_theta"):
+            rp = getattr(self, "rope_parameters", None) or {}
+            self.rope_theta = float(rp.get("rope_theta", kwargs.get("rope_theta", 10000.0)))
+
 
 class HipRMSNorm(nn.Module):
     def __init__(self, hidden_size, eps=1e-6, device=None, dtype=None):
