@@ -13,47 +13,12 @@
 //   * block id -> tile mapping is XCD-aware (8 XCDs, private L2s).
 //   * rows of A / C / residual / pre_out go through a 3-level row map so gathers such as the in-LLM
 //     slice hidden[:, 91:691].view(B,24,25,H)[:, :, :24] are folded into the loads.
-#include "common.h"
-#include "gemm_layout.h"
+#include <stdlib.h>
+#include "gemm_common.h"
+
+using namespace cmb_gemm_detail;
 
 namespace {
-
-struct GemmParams {
-  int M, N, K;
-  const char* A; RowMap a_map;
-  const char* B; int64_t ldb;
-  char* C; RowMap c_map;
-  const float* bias;
-  const float* colscale;
-  const char* R; RowMap r_map;
-  char* P; RowMap p_map;
-  int act;
-  float alpha, beta;
-  int out_f32;
-  int tiles_m, tiles_n;
-  int k_per_split;
-  float* slabs;
-};
-
-template <typename T> struct Mfma;
-template <> struct Mfma<bf16_t> {
-  typedef bf16x8_t frag_t;
-  static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mfma<float> {
-  typedef f32x4_t frag_t;
-  static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
-  }
-};
-
-__device__ __forceinline__ void glds16(const char* g, char* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
 
 template <int BM, int BN>
 constexpr int gemm_smem_bytes() {
@@ -206,48 +171,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
     }
-    if (p.slabs) {  // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
-      Vec8<float>::store(p.slabs + ((int64_t)kz * p.M + gm) * p.N + gn, v);
-      continue;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-    if (p.bias) {
-      float bb[8];
-      load8f(p.bias + gn, bb);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bb[e];
-    }
-    if (p.P) Vec8<T>::store(reinterpret_cast<T*>(p.P) + row_off(p.p_map, (uint32_t)gm) + gn, v);
-    if (p.act != CMB_ACT_NONE) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = act_apply(p.act, v[e]);
-    }
-    if (p.colscale) {
-      float ss[8];
-      load8f(p.colscale + gn, ss);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= ss[e];
-    }
-    if (p.R) {
-      float rr[8];
-      Vec8<T>::load(reinterpret_cast<const T*>(p.R) + row_off(p.r_map, (uint32_t)gm) + gn, rr);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += rr[e];
-    }
-    const int64_t coff = row_off(p.c_map, (uint32_t)gm) + gn;
-    if (p.out_f32) {
-      float* cp = reinterpret_cast<float*>(p.C) + coff;
-      if (p.beta != 0.0f) {
-        float old[8];
-        load8f(cp, old);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += p.beta * old[e];
-      }
-      Vec8<float>::store(cp, v);
-    } else {
-      Vec8<T>::store(reinterpret_cast<T*>(p.C) + coff, v);
-    }
+    gemm_epilogue8<T>(p, kz, gm, gn, v);
   }
 }
 
@@ -300,6 +224,32 @@ int launch_gemm(GemmParams& p, int splits, hipStream_t s) {
   return CMB_OK;
 }
 
+
+// Tile-configuration choice for bf16.  Cost unit = one "round" of the 256x256 kernel (256 workgroups, one per
+// CU).  Measured on full grids the 256x256 / 8-phase kernel is ~1.33x the 128x128 one (tools/bench_kernels.py:
+// 0.93-1.23 vs 0.70-0.90 PFLOP/s), and a round of 512 128x128 workgroups (two per CU) covers half the output of a
+// 256x256 round, so it costs 2 / 1.33 / 2 ~ 0.667 units; a last round of <= 256 such workgroups (one per CU, no
+// co-resident partner) ~0.6 of that.  cmb_gemm_desc.tile_hint / CMB_GEMM_TILE=128|256 override (tests, A-B).
+static int tile_override() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CMB_GEMM_TILE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+static bool use_tile256(int M, int N, int splits, int hint) {
+  const int ov = hint ? hint : tile_override();
+  if (ov == 256) return true;
+  if (ov == 128) return false;
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
+  const double c256 = (double)((t256 + 255) / 256);
+  const long rem = t128 % 512;
+  const double c128 = 0.667 * ((double)(t128 / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.6 : 1.0)));
+  return c256 <= c128;
+}
+
 template <typename T>
 int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   constexpr int BK = 128 / (int)sizeof(T);
@@ -336,7 +286,12 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
       p.k_per_split = p.K;
     }
   }
-  int rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+  int rc;
+  if constexpr (sizeof(T) == 2) {
+    rc = use_tile256(p.M, p.N, splits, d->tile_hint) ? launch_gemm256_bf16(p, splits, s) : launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+  } else {
+    rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+  }
   if (rc != CMB_OK) return rc;
   if (p.slabs) {
     const int64_t groups = (int64_t)p.M * (p.N / 8);

@@ -1,0 +1,279 @@
+// gemm256.hip — the large-tile configuration of C[M,N] = epilogue(alpha * A[M,K] · B[N,K]^T), bf16, for gfx950.
+//
+// Geometry: block tile 256 x 256, K-step 64 (128 B per operand row), 8 waves as
+// 2 (wr, along M) x 4 (wc, along N), one workgroup per CU, 128 KiB of LDS = 2 K-tile buffers x {A,B} x 2 halves of
+// 128 rows x 128 B.  The wave (wr, wc) owns the four 64 x 32 output "quadrants"
+//     rows  ra*128 + wr*64 + [0,64)   x   cols  cb*128 + wc*32 + [0,32)      (ra, cb in {0,1})
+// so that EVERY wave reads EVERY half-tile, each half-tile in exactly one phase of the K-step:
+//     phase q0: (ra0, cb0)  reads A-half0 (8 x ds_read_b128) + B-half0 (4)
+//     phase q1: (ra0, cb1)  reads B-half1 (4)
+//     phase q2: (ra1, cb1)  reads A-half1 (8)
+//     phase q3: (ra1, cb0)  reads nothing (B-half0 fragments are still live)
+// Each phase is { ds_read the fragments | issue ONE half-tile of LDS-DMA prefetch (2 x global_load_lds_dwordx4 per
+// lane) -> s_barrier -> lgkmcnt(0) -> 8 x v_mfma_f32_32x32x16_bf16 under s_setprio 1 -> s_barrier }.  The two wave
+// groups wr = 0 / wr = 1 (one wave of each per SIMD) run staggered by one barrier, so on every SIMD one wave is in
+// its MFMA segment while its partner is in its load segment (cdna_hip_programming.md §5 "8-phase template").
+//
+// Prefetch schedule (tile t lives in buffer t & 1; "p" = global phase index 4t + q):
+//     (t, q0): A-half1 of tile t+1        (t, q1): B-half0 of tile t+2 (issued AFTER the phase's first barrier)
+//     (t, q2): A-half0 of tile t+2        (t, q3): B-half1 of tile t+2, then s_waitcnt vmcnt(6)
+// RAW: the vmcnt(6) at (t, q3) leaves the 3 newest half-tiles (6 DMA instructions per lane) in flight, i.e. it
+//      retires everything issued up to (t, q0) = all of tile t+1; the wait precedes the phase's first barrier and
+//      tile t+1 is first read one phase later, which is safe for both wave groups (a reader departs a barrier that
+//      the staging wave reached after its wait).
+// WAR: a half-tile is re-staged >= 2 phases after the phase that read it (the reads are retired by lgkmcnt(0)
+//      before the reading phase's second barrier): A-half0 read q0 -> restaged q2; B-half1 read q1 -> restaged q3;
+//      A-half1 read q2 -> restaged q0 of the next tile.  B-half0 (read q0) is restaged in q1, one phase later, and
+//      is therefore issued after q1's FIRST barrier, which every wave reaches only after retiring its q0 reads.
+// Nothing else orders LDS-DMA against ds_read (MI355X_MICROARCH.md "Two waves per SIMD" item 7).
+//
+// LDS layout, swizzle and the LDS-DMA source permutation are those of gemm_layout.h (rows of 128 B, 16-B chunk c of
+// row r at ((c ^ ((r >> 1) & 7)) << 4): conflict-free ds_read_b128 under the gfx950 lane grouping).
+// Epilogue: each wave stages one quadrant at a time (64 x 32 fp32, row stride 36) in its PRIVATE 16 KiB slice of
+// the LDS (no workgroup barrier), and leaves through gemm_epilogue8 as row-contiguous 16/32-byte stores.
+#include <type_traits>
+#include "gemm_common.h"
+
+namespace cmb_gemm_detail {
+namespace {
+
+constexpr int kHalf = 16384;          // bytes of one half-tile (128 rows x 128 B)
+constexpr int kBuf = 4 * kHalf;       // one K-tile buffer: A0 A1 B0 B1
+constexpr int kSmem = 2 * kBuf;       // 128 KiB
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+#define CMB_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define CMB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__global__ void __launch_bounds__(512) gemm_nt_256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16x8_t frag_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int id = gl_xcd_remap((int)blockIdx.x, nblk);
+  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int kz = blockIdx.y;
+  const int kbeg = kz * p.k_per_split;
+  const int kend = (kbeg + p.k_per_split < p.K) ? (kbeg + p.k_per_split) : p.K;
+  const int nk = (kend > kbeg) ? (kend - kbeg) / 64 : 0;
+
+  // ---- per-lane LDS-DMA sources: half-tile h, DMA group g = wave + 8*i covers rows g*8 .. g*8+7 ------------
+  const char* a_src[2][2];
+  const char* b_src[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int grp = wave + 8 * i;
+      const int row = gl_dma_row(grp, lane), c = gl_dma_chunk(grp, lane);
+      int gm = m0 + h * 128 + row;
+      gm = gm < p.M ? gm : p.M - 1;
+      a_src[h][i] = p.A + (row_off(p.a_map, (uint32_t)gm) + kbeg) * 2 + c * 16;
+      int gn = n0 + h * 128 + row;
+      gn = gn < p.N ? gn : p.N - 1;
+      b_src[h][i] = p.B + ((int64_t)gn * p.ldb + kbeg) * 2 + c * 16;
+    }
+  char* const dma_dst = smem + wave * 1024;  // + buf*kBuf + half offset + i*8192
+
+  auto stage_a = [&](int buf, int h) {
+    glds16(a_src[h][0], dma_dst + buf * kBuf + h * kHalf);
+    glds16(a_src[h][1], dma_dst + buf * kBuf + h * kHalf + 8192);
+    a_src[h][0] += 128;
+    a_src[h][1] += 128;
+  };
+  auto stage_b = [&](int buf, int h) {
+    glds16(b_src[h][0], dma_dst + buf * kBuf + 2 * kHalf + h * kHalf);
+    glds16(b_src[h][1], dma_dst + buf * kBuf + 2 * kHalf + h * kHalf + 8192);
+    b_src[h][0] += 128;
+    b_src[h][1] += 128;
+  };
+
+  // ---- fragment read addresses: row (lane & 31) of a 32-row sub-tile, chunk 2*ks + (lane >> 5), swizzled ----
+  const int swz = (lane >> 1) & 7;  // == gl_swz(row) for every row this lane reads (row = 32*k + (lane & 31))
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = ((gl_frag_chunk(ks, lane) ^ swz) << 4);
+  const char* const a_rd = smem + (wr * 64 + (lane & 31)) * 128;              // + buf*kBuf + ra*kHalf + i*4096
+  const char* const b_rd = smem + 2 * kHalf + (wc * 32 + (lane & 31)) * 128;  // + buf*kBuf + cb*kHalf
+
+  f32x16_t acc[2][2][2];  // [ra][cb][i]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.0f;
+
+  frag_t fa[2][4];      // A fragments of the current row-half: [i][ks]
+  frag_t fb[2][4];      // B fragments: [cb][ks]
+
+  auto read_a = [&](int buf, int ra) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        fa[i][ks] = *reinterpret_cast<const frag_t*>(a_rd + buf * kBuf + ra * kHalf + i * 4096 + koff[ks]);
+  };
+  auto read_b = [&](int buf, int cb) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      fb[cb][ks] = *reinterpret_cast<const frag_t*>(b_rd + buf * kBuf + cb * kHalf + koff[ks]);
+  };
+  auto mfma_quadrant = [&](int ra, int cb) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)  // swapped operands: accumulator rows walk n, columns walk m
+        acc[ra][cb][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][ks], fa[i][ks], acc[ra][cb][i], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // one K-tile = 4 phases.  BUF is a compile-time constant so every LDS offset folds into an immediate.
+  auto ktile = [&](auto buf_c, int t) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const bool more1 = (t + 1 < nk), more2 = (t + 2 < nk);
+    // ---- q0: (ra0, cb0)
+    read_b(BUF, 0);
+    read_a(BUF, 0);
+    if (more1) stage_a(BUF ^ 1, 1);
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CMB_SCHED_FENCE();
+    mfma_quadrant(0, 0);
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    // ---- q1: (ra0, cb1)
+    read_b(BUF, 1);
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (more2) stage_b(BUF, 0);  // B-half0 was read one phase ago: only legal after this phase's first barrier
+    CMB_SCHED_FENCE();
+    mfma_quadrant(0, 1);
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    // ---- q2: (ra1, cb1)
+    read_a(BUF, 1);
+    if (more2) stage_a(BUF, 0);
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CMB_SCHED_FENCE();
+    mfma_quadrant(1, 1);
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    // ---- q3: (ra1, cb0)
+    if (more2) {
+      stage_b(BUF, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // retires all of tile t+1
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    CMB_SCHED_FENCE();
+    mfma_quadrant(1, 0);
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+  };
+
+  if (nk > 0) {
+    // prologue: all of tile 0, and B0 / A0 / B1 of tile 1 (its A1 goes out in phase (0, q0))
+    stage_a(0, 0);
+    stage_a(0, 1);
+    stage_b(0, 0);
+    stage_b(0, 1);
+    if (nk > 1) {
+      stage_b(1, 0);
+      stage_a(1, 0);
+      stage_b(1, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CMB_SCHED_FENCE();
+    CMB_BARRIER();
+    if (wr == 1) CMB_BARRIER();  // stagger the two wave groups by one barrier
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < nk; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, t);
+      ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nk) ktile(std::integral_constant<int, 0>{}, t);
+    if (wr == 0) CMB_BARRIER();  // re-align: every wave has now executed the same number of barriers
+  }
+
+  // ---- epilogue: quadrant -> private LDS slice (fp32, row stride 36) -> row-contiguous global stores -----------
+  constexpr int CS = 36;
+  float* cs = reinterpret_cast<float*>(smem + wave * 16384);
+  auto emit = [&](auto ra_c, auto cb_c) {
+    constexpr int ra = decltype(ra_c)::value, cb = decltype(cb_c)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4_t v;
+        v[0] = acc[ra][cb][i][4 * q + 0];
+        v[1] = acc[ra][cb][i][4 * q + 1];
+        v[2] = acc[ra][cb][i][4 * q + 2];
+        v[3] = acc[ra][cb][i][4 * q + 3];
+        *reinterpret_cast<f32x4_t*>(cs + (i * 32 + gl_acc_m(lane)) * CS + gl_acc_n(4 * q, lane)) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = it * 64 + lane;
+      const int row = item >> 2, c8 = item & 3;
+      const int gm = m0 + ra * 128 + wr * 64 + row;
+      const int gn = n0 + cb * 128 + wc * 32 + c8 * 8;
+      float v[8];
+      {
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8);
+        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      }
+      if (gm < p.M && gn < p.N) gemm_epilogue8<bf16_t>(p, kz, gm, gn, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next quadrant
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  emit(I0{}, I0{});
+  emit(I0{}, I1{});
+  emit(I1{}, I0{});
+  emit(I1{}, I1{});
+}
+
+}  // namespace
+
+int launch_gemm256_bf16(GemmParams& p, int splits, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) != hipSuccess)
+      return CMB_ERR_LAUNCH;
+    attr_done = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits);
+  hipLaunchKernelGGL(gemm_nt_256_kernel, grid, dim3(512), kSmem, s, p);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+}  // namespace cmb_gemm_detail

@@ -1,0 +1,98 @@
+// gemm_common.h — parameter block, MFMA wrappers and the fused row-contiguous epilogue shared by the two
+// tile configurations of the NT GEMM (gemm.hip: 128x128 / 4 waves; gemm256.hip: 256x256 / 8 waves, 8-phase).
+#pragma once
+#include "common.h"
+#include "gemm_layout.h"
+
+namespace cmb_gemm_detail {
+
+struct GemmParams {
+  int M, N, K;
+  const char* A; RowMap a_map;
+  const char* B; int64_t ldb;
+  char* C; RowMap c_map;
+  const float* bias;
+  const float* colscale;
+  const char* R; RowMap r_map;
+  char* P; RowMap p_map;
+  int act;
+  float alpha, beta;
+  int out_f32;
+  int tiles_m, tiles_n;
+  int k_per_split;
+  float* slabs;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  typedef bf16x8_t frag_t;
+  static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<float> {
+  typedef f32x4_t frag_t;
+  static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+
+// Fused epilogue on 8 consecutive columns of output row gm (fp32 values v[8] straight from the accumulators):
+// split-K slab store, or alpha/bias/pre_out/activation/LayerScale/residual/beta and the final store.
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int gm, int gn, float (&v)[8]) {
+  if (p.slabs) {  // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
+    Vec8<float>::store(p.slabs + ((int64_t)kz * p.M + gm) * p.N + gn, v);
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+  if (p.bias) {
+    float bb[8];
+    load8f(p.bias + gn, bb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bb[e];
+  }
+  if (p.P) Vec8<T>::store(reinterpret_cast<T*>(p.P) + row_off(p.p_map, (uint32_t)gm) + gn, v);
+  if (p.act != CMB_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_apply(p.act, v[e]);
+  }
+  if (p.colscale) {
+    float ss[8];
+    load8f(p.colscale + gn, ss);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= ss[e];
+  }
+  if (p.R) {
+    float rr[8];
+    Vec8<T>::load(reinterpret_cast<const T*>(p.R) + row_off(p.r_map, (uint32_t)gm) + gn, rr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+  }
+  const int64_t coff = row_off(p.c_map, (uint32_t)gm) + gn;
+  if (p.out_f32) {
+    float* cp = reinterpret_cast<float*>(p.C) + coff;
+    if (p.beta != 0.0f) {
+      float old[8];
+      load8f(cp, old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += p.beta * old[e];
+    }
+    Vec8<float>::store(cp, v);
+  } else {
+    Vec8<T>::store(reinterpret_cast<T*>(p.C) + coff, v);
+  }
+}
+
+// gemm256.hip: 256x256x64 bf16 tile, 8 waves, 8-phase schedule.  Returns CMB_OK / CMB_ERR_LAUNCH.
+int launch_gemm256_bf16(GemmParams& p, int splits, hipStream_t s);
+
+}  // namespace cmb_gemm_detail

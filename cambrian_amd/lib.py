@@ -46,6 +46,7 @@ class GemmDesc(C.Structure):
         ("pre_out", C.c_void_p), ("p_map", RowMap),
         ("act", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float),
         ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("tile_hint", C.c_int32),
     ]
 
 

@@ -52,7 +52,7 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
            residual: Optional[torch.Tensor] = None, r_map: Optional[RowMap] = None,
            out: Optional[torch.Tensor] = None, c_map: Optional[RowMap] = None, out_dtype: Optional[torch.dtype] = None,
            pre_out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
-           split_k: int = 1) -> torch.Tensor:
+           split_k: int = 1, tile: int = 0) -> torch.Tensor:
     """C[M,N] = epilogue(alpha * A[M,K] @ W[N,K]^T).  ``a`` is [M,K] (row stride a.stride(0)) unless an
     explicit ``a_map``/``M`` is given, in which case ``a`` is just the base tensor."""
     L.require_gpu(a, w, bias, colscale, residual, out, pre_out)
@@ -106,6 +106,7 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
         d.pre_out, d.p_map = None, L.identity_map(0)
     d.act, d.alpha, d.beta = act, alpha, beta
     d.split_k = split_k
+    d.tile_hint = tile
     ws = None
     if split_k > 1:
         ws = torch.empty((split_k * M * N,), dtype=torch.float32, device=a.device)

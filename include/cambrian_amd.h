@@ -66,6 +66,8 @@ int cmb_abi_version(void);
  * epilogue order:  v = alpha*acc + bias[n];  pre_out = v;  v = act(v);  v *= colscale[n];
  *                  v += residual[m,n];  v += beta*C_old[m,n] (fp32 C only);  C = v
  * requirements: K % (128 / sizeof(elem)) == 0; N % 8 == 0; 16-byte aligned rows.
+ * two tile configurations: 128x128 / 4 waves, and for bf16 256x256 / 8 waves with the
+ *   8-phase LDS-DMA schedule; `tile_hint` = 0 lets the library pick by grid fill.
  * split_k > 1: fp32 partial slabs go to `workspace` (split_k*M*N*4 bytes) and are reduced by a
  *   second kernel; only alpha/beta and out_dtype apply (used for weight gradients).
  * ---------------------------------------------------------------------------------------- */
@@ -84,6 +86,7 @@ typedef struct cmb_gemm_desc {
   float alpha, beta;
   int32_t split_k;
   void* workspace; int64_t workspace_bytes;
+  int32_t tile_hint;       /* 0 = choose by grid-fill cost model; 128 / 256 = force that block tile (bf16 only) */
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);

@@ -1,0 +1,113 @@
+"""GPU parity + race screen of the 256x256 / 8-phase GEMM configuration (cambrian_amd/csrc/gemm256.hip).
+
+Reference = fp32 matmul of the SAME bf16-rounded operands (so the only difference is the accumulation order);
+the 128x128 configuration of the same library is the second, independent check (bf16 outputs must agree to one
+bf16 ulp of the fp32 result).  Shapes cover every K-tile count parity (1, 2, 3, 4, 5, 16 tiles of 64), ragged M / N
+tails that clamp LDS-DMA source rows, split-K slabs, the fused epilogue and the row maps."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from cambrian_amd import ops, lib
+    return ops, lib
+
+
+SHAPES = [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 512, 256), (300, 264, 320), (1000, 2048, 1024),
+          (4616, 1024, 1024), (257, 8, 64), (33, 520, 128), (2048, 2048, 2048), (8 * 730, 1536, 1536)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm256_matches_fp32_reference(dev, M, N, K):
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
+    ref = a.float() @ w.float().T                      # fp32 on the GPU (rocBLAS), same rounded operands
+    out = ops.k_gemm(a, w, out_dtype=torch.float32, tile=256)
+    assert out.shape == (M, N)
+    err = (out - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-5, err                            # fp32 accumulation in a different order only
+    out128 = ops.k_gemm(a, w, out_dtype=torch.float32, tile=128)
+    assert (out - out128).abs().max().item() / ref.abs().max().item() < 2e-5
+
+
+def test_gemm256_race_screen(dev):
+    """The schedule's LDS-DMA / ds_read ordering is only as good as its barriers: identical launches must be
+    bit-identical, across many repetitions and while other work loads the chip."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(3)
+    for M, N, K in [(4096, 4096, 4096), (8 * 10944, 2048, 1024), (1024, 1024, 8192)]:
+        a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        w = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
+        first = ops.k_gemm(a, w, tile=256)
+        ref = ops.k_gemm(a, w, tile=128)
+        assert rel_err(first, ref.float()) < 1e-2
+        side = torch.randn(4096, 4096, device=dev)
+        s2 = torch.cuda.Stream()
+        for it in range(12):
+            with torch.cuda.stream(s2):               # uneven background load on a second stream
+                side = side @ side * 1e-4
+            out = ops.k_gemm(a, w, tile=256)
+            assert torch.equal(out, first), f"non-deterministic result on repetition {it} for {(M, N, K)}"
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("act", ["none", "gelu_erf", "silu"])
+def test_gemm256_epilogue(dev, act):
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 700, 520, 192
+    dt = torch.bfloat16
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, cs, res = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    a_, w_, res_ = a.to(dt).float(), w.to(dt).float(), res.to(dt).float()
+    pre = a_ @ w_.T * 0.5 + bias
+    fn = {"none": lambda x: x, "gelu_erf": F.gelu, "silu": F.silu}[act]
+    ref = fn(pre) * cs + res_
+    pre_out = torch.empty(M, N, dtype=dt, device=dev)
+    out = ops.k_gemm(a.to(dev, dt), w.to(dev, dt), bias=bias.to(dev), act=L.ACT_CODES[act], colscale=cs.to(dev),
+                     residual=res.to(dev, dt), pre_out=pre_out, alpha=0.5, tile=256)
+    assert rel_err(out, ref) < 1e-2
+    assert rel_err(pre_out, pre) < 1e-2
+
+
+def test_gemm256_splitk_fp32_accumulate(dev):
+    """Weight-gradient shape: small output, huge reduction, fp32 out with beta accumulate."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(5)
+    N, K, M = 1024, 1024, 8192                         # dW[N,K] = g^T[N,M] @ x^T[K,M]^T
+    gt = torch.randn(N, M, generator=g).to(torch.bfloat16).to(dev)
+    xt = torch.randn(K, M, generator=g).to(torch.bfloat16).to(dev)
+    ref = gt.float() @ xt.float().T
+    prev = torch.randn(N, K, generator=g).to(dev)
+    out = prev.clone()
+    ops.k_gemm(gt, xt, out=out, split_k=8, beta=1.0, tile=256)
+    assert ((out - (ref + prev)).abs().max() / ref.abs().max()).item() < 2e-5
+
+
+def test_gemm256_rowmaps(dev):
+    """In-LLM hook gather/scatter folded into the A / C / residual row maps (cambrian_llama.py:181-207)."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, S, H, side, p0 = 2, 700, 256, 24, 91
+    dt = torch.bfloat16
+    hidden = torch.randn(B, S, H, generator=g).to(dt)
+    w = (torch.randn(H, H, generator=g) * 0.1).to(dt)
+    rows = hidden[:, p0:p0 + side * (side + 1)].reshape(B, side, side + 1, H)[:, :, :side].reshape(-1, H).float()
+    ref_rows = rows @ w.float().T + rows
+    ref = hidden.float().clone()
+    ref[:, p0:p0 + side * (side + 1)].view(B, side, side + 1, H)[:, :, :side] = ref_rows.view(B, side, side, H)
+    hd, src = hidden.to(dev), hidden.to(dev).clone()
+    amap = L.make_map(side * side, side, S * H, (side + 1) * H, H)
+    base, sbase = hd.view(-1)[p0 * H:], src.view(-1)[p0 * H:]
+    ops.k_gemm(sbase, w.to(dev), M=B * side * side, a_map=amap, residual=base, r_map=amap, out=base, c_map=amap, tile=256)
+    assert rel_err(hd, ref) < 1e-2
+    mask = torch.ones(B, S, dtype=torch.bool)
+    mask[:, p0:p0 + side * (side + 1)].view(B, side, side + 1)[:, :, :side] = False
+    assert torch.equal(hd.cpu()[mask], hidden[mask])   # untouched rows bit-identical

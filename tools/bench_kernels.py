@@ -36,9 +36,12 @@ def bench_gemm():
         w = torch.randn(N, K, device=dev).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         t = timeit(lambda: ops.k_gemm(a, w, out=out))
+        t128 = timeit(lambda: ops.k_gemm(a, w, out=out, tile=128))
+        t256 = timeit(lambda: ops.k_gemm(a, w, out=out, tile=256))
         t_ref = timeit(lambda: torch.matmul(a, w.T, out=out))
         fl = 2.0 * M * N * K
         print(json.dumps({"kernel": "gemm_bf16", "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
+                          "tile128_TFLOPs": fl / t128 / 1e12, "tile256_TFLOPs": fl / t256 / 1e12,
                           "hipblaslt_TFLOPs": fl / t_ref / 1e12}), flush=True)
     a = torch.randn(4096, 4096, device=dev)
     w = torch.randn(4096, 4096, device=dev)
