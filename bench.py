@@ -109,6 +109,18 @@ def cpu_baseline():
                       f"{step_gflop:.0f} GFLOP/img (towers fwd + 3x SVA side)"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    MI355X_MICROARCH.md §HBM), collected by tools/pmc_traffic.sh over this same command and committed under profiles/;
+    null when no PMC summary for the current round is present."""
+    path = os.path.join(ROOT, "profiles", "pmc_gemm256.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     from cambrian_amd.train.dp import GradSync, init_distributed
@@ -186,14 +198,24 @@ def main():
         if args.llm_layers is not None:
             line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"
         if prof:
-            flops = sum(f for _, _, f, dt_, _ in prof if dt_ == torch.bfloat16)
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _, dt_, _ in prof if dt_ == torch.bfloat16)
-            n = sum(1 for x in prof if x[3] == torch.bfloat16)
-            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16,128,128,2,2>", "achieved": ach,
-                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                                "traffic": None, "launches": n, "avg_launch_us": ms * 1e3 / max(n, 1),
-                                "gemm_share_of_step": ms / (elapsed * 1e3)}
+            # dominant HIP kernel of the hot path = the 256x256 / 8-phase bf16 MFMA GEMM: algorithmic FLOPs (2*M*N*K)
+            # of every launch of it in the timed region / its HIP-event time on the launch stream
+            def agg(sel):
+                fl = sum(x[2] for x in prof if sel(x))
+                ms = sum(x[0].elapsed_time(x[1]) for x in prof if sel(x))
+                n = sum(1 for x in prof if sel(x))
+                return fl, ms, n
+            f256, ms256, n256 = agg(lambda x: x[3] == torch.bfloat16 and x[5] == 256)
+            fall, msall, nall = agg(lambda x: x[3] == torch.bfloat16)
+            ach = f256 / (ms256 * 1e-3) / 1e12 if ms256 > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "kernel": "cmb_gemm_detail::gemm_nt_256_kernel (bf16, 256x256x64, 8 waves)",
+                                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                                "launches": n256, "avg_launch_us": ms256 * 1e3 / max(n256, 1),
+                                "flop_per_launch_avg": f256 / max(n256, 1),
+                                "share_of_step": ms256 / (elapsed * 1e3),
+                                "all_bf16_gemm": {"achieved": fall / (msall * 1e-3) / 1e12 if msall > 0 else 0.0,
+                                                  "launches": nall, "share_of_step": msall / (elapsed * 1e3)}}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -310,6 +310,11 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint) {
+  if (dtype != CMB_BF16) return 128;
+  return use_tile256((int)M, (int)N, split_k > 1 ? split_k : 1, tile_hint) ? 256 : 128;
+}
+
 extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return CMB_ERR_BAD_ARG;
   if (d->M < 0 || d->N <= 0 || d->K <= 0) return CMB_ERR_BAD_ARG;

@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(512) gemm_nt_256_kernel(const GemmParams p) {
   // ---- epilogue: quadrant -> private LDS slice (fp32, row stride 36) -> row-contiguous global stores -----------
   constexpr int CS = 36;
   float* cs = reinterpret_cast<float*>(smem + wave * 16384);
-  auto emit = [&](auto ra_c, auto cb_c) {
+  // The per-element epilogue code exists ONCE (runtime loops): fully unrolled it is ~100 KB of straight-line
+  // code that every wave streams through the instruction cache exactly once per tile.
+  auto put = [&](auto ra_c, auto cb_c) {
     constexpr int ra = decltype(ra_c)::value, cb = decltype(cb_c)::value;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -232,8 +234,18 @@ __global__ void __launch_bounds__(512) gemm_nt_256_kernel(const GemmParams p) {
         v[3] = acc[ra][cb][i][4 * q + 3];
         *reinterpret_cast<f32x4_t*>(cs + (i * 32 + gl_acc_m(lane)) * CS + gl_acc_n(4 * q, lane)) = v;
       }
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+#pragma unroll 1
+  for (int qd = 0; qd < 4; ++qd) {
+    const int ra = qd >> 1, cb = qd & 1;
+    if (qd == 0) put(I0{}, I0{});
+    else if (qd == 1) put(I0{}, I1{});
+    else if (qd == 2) put(I1{}, I0{});
+    else put(I1{}, I1{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < 4; ++it) {
       const int item = it * 64 + lane;
       const int row = item >> 2, c8 = item & 3;
@@ -249,13 +261,7 @@ __global__ void __launch_bounds__(512) gemm_nt_256_kernel(const GemmParams p) {
       if (gm < p.M && gn < p.N) gemm_epilogue8<bf16_t>(p, kz, gm, gn, v);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next quadrant
-  };
-  typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, 1> I1;
-  emit(I0{}, I0{});
-  emit(I0{}, I1{});
-  emit(I1{}, I0{});
-  emit(I1{}, I1{});
+  }
 }
 
 }  // namespace

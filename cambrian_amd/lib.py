@@ -74,6 +74,7 @@ SIGNATURES = {
     "cmb_version": (C.c_char_p, []),
     "cmb_abi_version": (C.c_int, []),
     "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
+    "cmb_gemm_tile": (C.c_int, [C.c_int, _i64, _i64, _i32, _i32]),
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_cast": (C.c_int, [C.c_int, _p, C.c_int, _p, _i64, _p]),

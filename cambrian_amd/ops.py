@@ -122,11 +122,12 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, dt, split_k))
+        prof.append((e0, e1, 2.0 * M * N * K, dt, split_k,
+                     L.load().cmb_gemm_tile(d.dtype, M, N, split_k, tile)))
     return out
 
 
-# bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k) per GEMM launch
+# bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k, tile) per GEMM launch
 GEMM_PROFILE = None
 
 

@@ -90,6 +90,9 @@ typedef struct cmb_gemm_desc {
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);
+/* block tile (128 or 256) cmb_gemm would run for this problem — lets the caller label profiles / rooflines per
+ * kernel configuration.  dtype CMB_F32 always answers 128. */
+int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint);
 
 /* out[C, R_pad] = in[R, C]^T, zero-filling columns R..R_pad-1 (R_pad >= R). Used to put the
  * reduction dimension innermost for weight-gradient GEMMs (autograd of the linears above). */

@@ -1,0 +1,47 @@
+"""CPU: the erf() minimax polynomials of cambrian_amd/csrc/common.h (cmb_erf), re-evaluated in float32 numpy with the
+coefficients PARSED FROM THE HEADER, against math.erf on a dense grid — the GELU of the reference is the exact-erf
+nn.GELU() (vision_sampler.py:241, cambrian_arch.py:56), so the device approximation must stay within fp32 round-off."""
+import math
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _coeffs():
+    src = open(os.path.join(ROOT, "cambrian_amd", "csrc", "common.h")).read()
+    body = src[src.index("float cmb_erf(float a)"):]
+    body = body[:body.index("return t >")]
+    nums = [float(x.rstrip("f")) for x in re.findall(r"-?\d\.\d+e-\d+f", body)]
+    assert len(nums) == 13, nums
+    thr = float(re.search(r"return t > (\d\.\d+)f", src).group(1))
+    return nums, thr
+
+
+def test_cmb_erf_polynomials_within_one_ulp():
+    c, thr = _coeffs()
+    f = np.float32
+
+    def fma(a, b, cc):
+        return (np.float64(a) * np.float64(b) + np.float64(cc)).astype(np.float32)
+
+    x = np.concatenate([np.linspace(-6, 6, 400001), np.random.default_rng(0).normal(size=200000) * 2]).astype(f)
+    t, s = np.abs(x), (x * x).astype(f)
+    r = fma(np.full_like(x, f(c[0])), t, f(c[1]))
+    u = fma(np.full_like(x, f(c[2])), t, f(c[3]))
+    r = fma(r, s, u)
+    for k in (c[4], c[5], c[6]):
+        r = fma(r, t, f(k))
+    r = fma(r, t, -t)
+    big = np.copysign((1.0 - np.exp(r.astype(np.float64))).astype(f), x)
+    q = np.full_like(x, f(c[7]))
+    for k in c[8:13]:
+        q = fma(q, s, f(k))
+    small = fma(q, x, x)
+    got = np.where(t > f(thr), big, small).astype(np.float64)
+    ref = np.array([math.erf(float(v)) for v in x])
+    err = np.abs(got - ref)
+    assert err.max() < 1.2e-7, err.max()
+    assert (err / np.maximum(np.abs(ref), 1e-30)).max() < 2e-7
