@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p
 
   const int nblk = p.tiles_m * p.tiles_n;
   const int id = gl_xcd_remap((int)blockIdx.x, nblk);
-  const int tile_m = id / p.tiles_n, tile_n = id - tile_m * p.tiles_n;
+  int tile_m, tile_n;
+  gl_group_tile(id, p.tiles_m, p.tiles_n, 8, &tile_m, &tile_n);  // 64 resident workgroups per XCD = 8 x 8 tiles
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kz = blockIdx.y;
   const int kbeg = kz * p.k_per_split;
@@ -240,7 +241,7 @@ static int tile_override() {
 }
 static bool use_tile256(int M, int N, int splits, int hint) {
   const int ov = hint ? hint : tile_override();
-  if (ov == 256) return true;
+  if (ov == 256 || ov == 2560 || ov == 2561) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -288,7 +289,7 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   }
   int rc;
   if constexpr (sizeof(T) == 2) {
-    rc = use_tile256(p.M, p.N, splits, d->tile_hint) ? launch_gemm256_bf16(p, splits, s) : launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+    rc = use_tile256(p.M, p.N, splits, d->tile_hint) ? launch_gemm256_bf16(p, splits, d->tile_hint == 2561 ? 1 : 0, s) : launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   } else {
     rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   }

@@ -93,6 +93,7 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
 }
 
 // gemm256.hip: 256x256x64 bf16 tile, 8 waves, 8-phase schedule.  Returns CMB_OK / CMB_ERR_LAUNCH.
-int launch_gemm256_bf16(GemmParams& p, int splits, hipStream_t s);
+// sched: 0 = 8-phase ping-pong (two barriers per phase), 1 = in-wave pipeline (one barrier per K-tile).
+int launch_gemm256_bf16(GemmParams& p, int splits, int sched, hipStream_t s);
 
 }  // namespace cmb_gemm_detail

@@ -51,6 +51,19 @@ CMB_HD int gl_frag_chunk(int ks, int lane) { return 2 * ks + (lane >> 5); }
 CMB_HD int gl_acc_m(int lane) { return lane & 31; }
 CMB_HD int gl_acc_n(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// Grouped rasterisation of a linear tile id: tiles are walked column by column inside bands of `group_m` tile
+// rows, so the ~32 (64) workgroups resident on one XCD at a time form a compact group_m x (32/group_m) patch of the
+// output and share A row panels / B column panels in that XCD's 4 MiB L2 instead of streaming one whole row of
+// tiles (which re-fetches all of B for every row panel).
+CMB_HD void gl_group_tile(int id, int tiles_m, int tiles_n, int group_m, int* tm, int* tn) {
+  const int width = group_m * tiles_n;
+  const int group = id / width, rem = id - group * width;
+  const int first = group * group_m;
+  const int gsize = (tiles_m - first) < group_m ? (tiles_m - first) : group_m;
+  *tm = first + rem % gsize;
+  *tn = rem / gsize;
+}
+
 // XCD-aware bijective remap of the linear block id (cdna_hip_programming.md §5 template): hardware
 // places block b on XCD b % 8; give every XCD a contiguous range of tiles so neighbouring tiles
 // (same A row panel) share that XCD's L2.

@@ -86,7 +86,8 @@ typedef struct cmb_gemm_desc {
   float alpha, beta;
   int32_t split_k;
   void* workspace; int64_t workspace_bytes;
-  int32_t tile_hint;       /* 0 = choose by grid-fill cost model; 128 / 256 = force that block tile (bf16 only) */
+  int32_t tile_hint;       /* 0 = choose by grid-fill cost model; 128 / 256 = force that block tile (bf16 only);
+                              2560 / 2561 = 256 tile with schedule 0 (8-phase ping-pong, default) / 1 (in-wave pipeline) */
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);

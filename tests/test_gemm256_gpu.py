@@ -22,14 +22,18 @@ SHAPES = [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 512, 256), (30
           (4616, 1024, 1024), (257, 8, 64), (33, 520, 128), (2048, 2048, 2048), (8 * 730, 1536, 1536)]
 
 
+SCHEDS = [2560, 2561]  # tile_hint: 256x256 tile, schedule 0 (8-phase ping-pong) / 1 (in-wave pipeline, 1 barrier per K-tile)
+
+
+@pytest.mark.parametrize("tile", SCHEDS)
 @pytest.mark.parametrize("M,N,K", SHAPES)
-def test_gemm256_matches_fp32_reference(dev, M, N, K):
+def test_gemm256_matches_fp32_reference(dev, M, N, K, tile):
     ops, L = _ops()
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     w = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
     ref = a.float() @ w.float().T                      # fp32 on the GPU (rocBLAS), same rounded operands
-    out = ops.k_gemm(a, w, out_dtype=torch.float32, tile=256)
+    out = ops.k_gemm(a, w, out_dtype=torch.float32, tile=tile)
     assert out.shape == (M, N)
     err = (out - ref).abs().max().item() / ref.abs().max().item()
     assert err < 2e-5, err                            # fp32 accumulation in a different order only
@@ -37,7 +41,8 @@ def test_gemm256_matches_fp32_reference(dev, M, N, K):
     assert (out - out128).abs().max().item() / ref.abs().max().item() < 2e-5
 
 
-def test_gemm256_race_screen(dev):
+@pytest.mark.parametrize("tile", SCHEDS)
+def test_gemm256_race_screen(dev, tile):
     """The schedule's LDS-DMA / ds_read ordering is only as good as its barriers: identical launches must be
     bit-identical, across many repetitions and while other work loads the chip."""
     ops, L = _ops()
@@ -45,7 +50,7 @@ def test_gemm256_race_screen(dev):
     for M, N, K in [(4096, 4096, 4096), (8 * 10944, 2048, 1024), (1024, 1024, 8192)]:
         a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
         w = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
-        first = ops.k_gemm(a, w, tile=256)
+        first = ops.k_gemm(a, w, tile=tile)
         ref = ops.k_gemm(a, w, tile=128)
         assert rel_err(first, ref.float()) < 1e-2
         side = torch.randn(4096, 4096, device=dev)
@@ -53,13 +58,14 @@ def test_gemm256_race_screen(dev):
         for it in range(12):
             with torch.cuda.stream(s2):               # uneven background load on a second stream
                 side = side @ side * 1e-4
-            out = ops.k_gemm(a, w, tile=256)
+            out = ops.k_gemm(a, w, tile=tile)
             assert torch.equal(out, first), f"non-deterministic result on repetition {it} for {(M, N, K)}"
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("tile", SCHEDS)
 @pytest.mark.parametrize("act", ["none", "gelu_erf", "silu"])
-def test_gemm256_epilogue(dev, act):
+def test_gemm256_epilogue(dev, act, tile):
     ops, L = _ops()
     g = torch.Generator().manual_seed(11)
     M, N, K = 700, 520, 192
@@ -72,12 +78,13 @@ def test_gemm256_epilogue(dev, act):
     ref = fn(pre) * cs + res_
     pre_out = torch.empty(M, N, dtype=dt, device=dev)
     out = ops.k_gemm(a.to(dev, dt), w.to(dev, dt), bias=bias.to(dev), act=L.ACT_CODES[act], colscale=cs.to(dev),
-                     residual=res.to(dev, dt), pre_out=pre_out, alpha=0.5, tile=256)
+                     residual=res.to(dev, dt), pre_out=pre_out, alpha=0.5, tile=tile)
     assert rel_err(out, ref) < 1e-2
     assert rel_err(pre_out, pre) < 1e-2
 
 
-def test_gemm256_splitk_fp32_accumulate(dev):
+@pytest.mark.parametrize("tile", SCHEDS)
+def test_gemm256_splitk_fp32_accumulate(dev, tile):
     """Weight-gradient shape: small output, huge reduction, fp32 out with beta accumulate."""
     ops, L = _ops()
     g = torch.Generator().manual_seed(5)
@@ -87,11 +94,12 @@ def test_gemm256_splitk_fp32_accumulate(dev):
     ref = gt.float() @ xt.float().T
     prev = torch.randn(N, K, generator=g).to(dev)
     out = prev.clone()
-    ops.k_gemm(gt, xt, out=out, split_k=8, beta=1.0, tile=256)
+    ops.k_gemm(gt, xt, out=out, split_k=8, beta=1.0, tile=tile)
     assert ((out - (ref + prev)).abs().max() / ref.abs().max()).item() < 2e-5
 
 
-def test_gemm256_rowmaps(dev):
+@pytest.mark.parametrize("tile", SCHEDS)
+def test_gemm256_rowmaps(dev, tile):
     """In-LLM hook gather/scatter folded into the A / C / residual row maps (cambrian_llama.py:181-207)."""
     ops, L = _ops()
     g = torch.Generator().manual_seed(5)
@@ -106,7 +114,7 @@ def test_gemm256_rowmaps(dev):
     hd, src = hidden.to(dev), hidden.to(dev).clone()
     amap = L.make_map(side * side, side, S * H, (side + 1) * H, H)
     base, sbase = hd.view(-1)[p0 * H:], src.view(-1)[p0 * H:]
-    ops.k_gemm(sbase, w.to(dev), M=B * side * side, a_map=amap, residual=base, r_map=amap, out=base, c_map=amap, tile=256)
+    ops.k_gemm(sbase, w.to(dev), M=B * side * side, a_map=amap, residual=base, r_map=amap, out=base, c_map=amap, tile=tile)
     assert rel_err(hd, ref) < 1e-2
     mask = torch.ones(B, S, dtype=torch.bool)
     mask[:, p0:p0 + side * (side + 1)].view(B, side, side + 1)[:, :, :side] = False

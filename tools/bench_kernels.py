@@ -37,23 +37,25 @@ def bench_gemm():
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         t = timeit(lambda: ops.k_gemm(a, w, out=out))
         t128 = timeit(lambda: ops.k_gemm(a, w, out=out, tile=128))
-        t256 = timeit(lambda: ops.k_gemm(a, w, out=out, tile=256))
+        t256 = timeit(lambda: ops.k_gemm(a, w, out=out, tile=2560))
+        t256b = timeit(lambda: ops.k_gemm(a, w, out=out, tile=2561))
         t_ref = timeit(lambda: torch.matmul(a, w.T, out=out))
         fl = 2.0 * M * N * K
         print(json.dumps({"kernel": "gemm_bf16", "M": M, "N": N, "K": K, "ms": t * 1e3, "TFLOPs": fl / t / 1e12,
-                          "tile128_TFLOPs": fl / t128 / 1e12, "tile256_TFLOPs": fl / t256 / 1e12,
-                          "hipblaslt_TFLOPs": fl / t_ref / 1e12}), flush=True)
+                          "tile128_TFLOPs": fl / t128 / 1e12, "tile256s0_TFLOPs": fl / t256 / 1e12,
+                          "tile256s1_TFLOPs": fl / t256b / 1e12, "hipblaslt_TFLOPs": fl / t_ref / 1e12}), flush=True)
     for M, N, K in [(8 * 4096, 6144, 1536), (8 * 65536, 1536, 384)]:  # ConvNeXt fc1: bias + exact-erf GELU epilogue
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = torch.randn(N, K, device=dev).to(torch.bfloat16)
         b = torch.randn(N, device=dev)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         r = {}
-        for tile in (128, 256):
+        for tile in (128, 2560, 2561):
             r[tile] = timeit(lambda: ops.k_gemm(a, w, out=out, bias=b, act=L.ACT_GELU_ERF, tile=tile))
         fl = 2.0 * M * N * K
         print(json.dumps({"kernel": "gemm_bf16_bias_gelu", "M": M, "N": N, "K": K,
-                          "tile128_TFLOPs": fl / r[128] / 1e12, "tile256_TFLOPs": fl / r[256] / 1e12}), flush=True)
+                          "tile128_TFLOPs": fl / r[128] / 1e12, "tile256s0_TFLOPs": fl / r[2560] / 1e12,
+                          "tile256s1_TFLOPs": fl / r[2561] / 1e12}), flush=True)
     a = torch.randn(4096, 4096, device=dev)
     w = torch.randn(4096, 4096, device=dev)
     t = timeit(lambda: ops.k_gemm(a, w), iters=5)
