@@ -49,6 +49,7 @@ def parse():
                     help="images per GPU per step (reference: per_device_train_batch_size 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-report", type=str, default=None, help="write a per-shape table of the hot-path GEMM launches (JSON)")
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (marks the line INVALID)")
     return ap.parse_args()
 
@@ -58,6 +59,7 @@ def build_model(dev, llm_layers=None):
                                                                 llama3_8b_config)
     cfg = llama3_8b_config() if llm_layers is None else llama3_8b_config(num_hidden_layers=llm_layers)
     apply_release_8b_vision_config(cfg)
+    cfg.fused_loss = True  # fp32 log-sum-exp over the bf16 logits, no logits.float() copy (same loss / gradients)
     torch.manual_seed(0)
     model = CambrianLlamaForCausalLM(cfg, device=dev, llm_dtype=torch.bfloat16)
     with torch.no_grad():
@@ -216,6 +218,20 @@ def main():
                                 "share_of_step": ms256 / (elapsed * 1e3),
                                 "all_bf16_gemm": {"achieved": fall / (msall * 1e-3) / 1e12 if msall > 0 else 0.0,
                                                   "launches": nall, "share_of_step": msall / (elapsed * 1e3)}}
+        if prof and args.gemm_report:
+            shapes = {}
+            for x in prof:
+                key = (x[6], x[4], x[5])
+                s_ = shapes.setdefault(key, [0, 0.0, 0.0])
+                s_[0] += 1
+                s_[1] += x[0].elapsed_time(x[1])
+                s_[2] += x[2]
+            rows = [{"M": k[0][0], "N": k[0][1], "K": k[0][2], "act": k[0][3], "f32_out": k[0][4], "split_k": k[1], "tile": k[2],
+                     "launches_per_step": v[0] / args.steps, "ms_per_step": v[1] / args.steps,
+                     "TFLOPs": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in shapes.items()]
+            rows.sort(key=lambda r: -r["ms_per_step"])
+            with open(args.gemm_report, "w") as f:
+                json.dump(rows, f, indent=0)
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -64,7 +64,7 @@ class LlamaMLP(nn.Module):
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, **kw)
 
     def forward(self, x):
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+        return self.down_proj(ops.swiglu(self.gate_proj(x), self.up_proj(x)))
 
 
 class LlamaAttention(nn.Module):
@@ -218,12 +218,24 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
         if sva is not None and not isinstance(sva, SvaContext):
             raise TypeError("this decoder consumes the fused SvaContext (config.sva_fused = True)")
         hidden = self.model(inputs_embeds.to(self.model.llm_dtype), position_ids, attention_mask, sva)
-        logits = self.lm_head(hidden).float()                                        # :402-409
+        logits = self.lm_head(hidden)                                                # :402-408
         loss = None
-        if labels is not None:                                                       # :411-422
-            shift_logits = logits[..., :-1, :].contiguous().view(-1, self.vocab_size)
-            shift_labels = labels[..., 1:].contiguous().view(-1).to(shift_logits.device)
-            loss = F.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX)
+        if labels is not None and getattr(self.config, "fused_loss", False):
+            # :409-422 without logits.float() / the shifted copy: labels are shifted instead of the logits (position
+            # t is scored against labels[t+1], the last position of every sequence is ignored), fp32 log-sum-exp over
+            # the bf16 logits in one pass, dlogits written in place of the logits in the backward.  ``logits`` is then
+            # returned in the compute dtype (its .float() is the reference's tensor) and is consumed by backward().
+            B_, S_, V_ = logits.shape
+            shift_labels = torch.full_like(labels, IGNORE_INDEX)
+            shift_labels[:, :-1] = labels[:, 1:]
+            loss = ops.cross_entropy(logits.view(B_ * S_, V_), shift_labels.view(-1).to(logits.device), IGNORE_INDEX,
+                                     inplace=True)
+        else:
+            logits = logits.float()                                                  # :409
+            if labels is not None:                                                   # :411-422
+                shift_logits = logits[..., :-1, :].contiguous().view(-1, self.vocab_size)
+                shift_labels = labels[..., 1:].contiguous().view(-1).to(shift_logits.device)
+                loss = F.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX)
         if CausalLMOutputWithPast is not None:
             return CausalLMOutputWithPast(loss=loss, logits=logits)
         return {"loss": loss, "logits": logits}

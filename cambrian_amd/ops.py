@@ -123,7 +123,7 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K, dt, split_k,
-                     L.load().cmb_gemm_tile(d.dtype, M, N, split_k, tile)))
+                     L.load().cmb_gemm_tile(d.dtype, M, N, split_k, tile), (M, N, K, act, out.dtype == torch.float32)))
     return out
 
 
@@ -723,3 +723,87 @@ def gather_query_rows(hidden, pos: int, side: int):
 
 def scatter_query_rows(hidden, rows, pos: int, side: int):
     return ScatterQueryRowsFn.apply(hidden, rows, pos, side)
+
+
+# ================================================================================================
+# autograd: fused shifted cross-entropy and SwiGLU (LLM side; cambrian_llama.py:402-422, Llama MLP)
+# ================================================================================================
+class CrossEntropyFn(torch.autograd.Function):
+    """mean_{labels != ignore} ( logsumexp(logits[t]) - logits[t, labels[t]] ) over [T, V] logits kept in their
+    compute dtype (the reference's ``logits.float()`` + ``CrossEntropyLoss``, cambrian_llama.py:409-422: fp32 math on
+    the same bf16-rounded values).  The backward overwrites ``logits`` with dlogits when ``inplace`` (the tensor that
+    lm_head produced is not needed by anybody else's backward)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index: int, inplace: bool):
+        L.require_gpu(logits, labels)
+        T, V = logits.shape
+        if logits.stride(1) != 1:
+            raise L.CambrianAmdError("logits must be row-major")
+        labels = labels.to(torch.int64).contiguous()
+        lse = torch.empty((T,), dtype=torch.float32, device=logits.device)
+        loss_rows = torch.empty((T,), dtype=torch.float32, device=logits.device)
+        rc = L.load().cmb_cross_entropy_fwd(L.dtype_code(logits.dtype), logits.data_ptr(), T, V, logits.stride(0),
+                                            labels.data_ptr(), ignore_index, lse.data_ptr(), loss_rows.data_ptr(),
+                                            L.stream_ptr(logits.device))
+        L.check(rc, "cmb_cross_entropy_fwd")
+        n_valid = (labels != ignore_index).sum().to(torch.float32)
+        ctx.save_for_backward(logits, labels, lse, n_valid)
+        ctx.ignore_index, ctx.inplace = ignore_index, inplace
+        return loss_rows.sum() / n_valid
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse, n_valid = ctx.saved_tensors
+        T, V = logits.shape
+        scale = (g.to(torch.float32) / n_valid).reshape(1).contiguous()
+        out = logits if ctx.inplace else torch.empty_like(logits)
+        rc = L.load().cmb_cross_entropy_bwd(L.dtype_code(logits.dtype), logits.data_ptr(), T, V, logits.stride(0),
+                                            labels.data_ptr(), ctx.ignore_index, lse.data_ptr(), scale.data_ptr(),
+                                            out.data_ptr(), out.stride(0), L.stream_ptr(logits.device))
+        L.check(rc, "cmb_cross_entropy_bwd")
+        return out, None, None, None
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100, inplace: bool = False):
+    return CrossEntropyFn.apply(logits, labels, ignore_index, inplace)
+
+
+class SwiGLUFn(torch.autograd.Function):
+    """h = silu(g) * u in one pass; backward (dg, du) in one pass (Llama MLP: down_proj(silu(gate) * up))."""
+
+    @staticmethod
+    def forward(ctx, g, u):
+        L.require_gpu(g, u)
+        shape = g.shape
+        D = shape[-1]
+        g2, u2 = g.reshape(-1, D), u.reshape(-1, D)
+        if g2.stride(1) != 1 or u2.stride(1) != 1:
+            g2, u2 = g2.contiguous(), u2.contiguous()
+        rows = g2.shape[0]
+        h = torch.empty((rows, D), dtype=g.dtype, device=g.device)
+        rc = L.load().cmb_act_mul(L.dtype_code(g.dtype), L.ACT_SILU, g2.data_ptr(), g2.stride(0), u2.data_ptr(), u2.stride(0),
+                                  rows, D, h.data_ptr(), D, L.stream_ptr(g.device))
+        L.check(rc, "cmb_act_mul(silu)")
+        ctx.save_for_backward(g2, u2)
+        ctx.shape = shape
+        return h.view(shape)
+
+    @staticmethod
+    def backward(ctx, dh):
+        g2, u2 = ctx.saved_tensors
+        rows, D = g2.shape
+        dh2 = dh.reshape(rows, D)
+        if dh2.stride(1) != 1:
+            dh2 = dh2.contiguous()
+        dg = torch.empty((rows, D), dtype=g2.dtype, device=g2.device)
+        du = torch.empty((rows, D), dtype=g2.dtype, device=g2.device)
+        rc = L.load().cmb_swiglu_bwd(L.dtype_code(g2.dtype), dh2.data_ptr(), dh2.stride(0), g2.data_ptr(), g2.stride(0),
+                                     u2.data_ptr(), u2.stride(0), rows, D, dg.data_ptr(), D, du.data_ptr(), D,
+                                     L.stream_ptr(g2.device))
+        L.check(rc, "cmb_swiglu_bwd")
+        return dg.view(ctx.shape), du.view(ctx.shape)
+
+
+def swiglu(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    return SwiGLUFn.apply(g, u)

@@ -256,6 +256,25 @@ int cmb_copy_rows(int dtype, const void* src, const cmb_rowmap* src_map, void* d
 int cmb_bcast_rows(int dtype, void* dst, int64_t ld, int64_t nrows, int64_t D, const void* src,
                    void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LLM-side HBM-bound kernels (llm_ops.hip)
+ * ---------------------------------------------------------------------------------------- */
+/* Shifted cross-entropy of cambrian_llama.py:411-422 without materialising logits.float():
+ * logits [rows, V] (bf16 or fp32, row stride ld), labels int64 [rows] ALREADY shifted by the caller
+ * (labels_shift[b, t] = labels[b, t+1], last position = ignore_index).  fwd: lse[row] = log sum_v exp(x_v) in fp32,
+ * loss[row] = lse - x[label] (0 for ignored rows); the caller reduces mean over the non-ignored rows.
+ * bwd: dlogits[row, v] = (exp(x_v - lse[row]) - [v == label]) * scale[0], zeros for ignored rows; dlogits may alias
+ * logits (in-place).  Rows that are not 16-byte aligned (odd vocabularies) take a scalar path. */
+int cmb_cross_entropy_fwd(int dtype, const void* logits, int64_t rows, int64_t V, int64_t ld,
+                          const int64_t* labels, int64_t ignore_index, float* lse, float* loss, void* stream);
+int cmb_cross_entropy_bwd(int dtype, const void* logits, int64_t rows, int64_t V, int64_t ld,
+                          const int64_t* labels, int64_t ignore_index, const float* lse, const float* scale,
+                          void* dlogits, int64_t ldd, void* stream);
+/* Backward of h = silu(g) * u (Llama MLP gate; forward is cmb_act_mul with CMB_ACT_SILU):
+ * dg = dh * u * silu'(g), du = dh * silu(g); all [rows, D] with row strides. */
+int cmb_swiglu_bwd(int dtype, const void* dh, int64_t lddh, const void* g, int64_t ldg, const void* u, int64_t ldu,
+                   int64_t rows, int64_t D, void* dg, int64_t lddg, void* du, int64_t lddu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -402,3 +402,49 @@ def test_act_kernels(dev, name, dt):
     rc = L.load().cmb_act_bwd(L.dtype_code(dt), L.ACT_GELU_ERF, ones.data_ptr(), hd.data_ptr(), hd.numel(),
                               dx.data_ptr(), L.stream_ptr(dev))
     assert rc == 0 and rel_err(dx, pre.grad) < TOL[name]
+
+
+# ------------------------------------------------------------------------------------------------ LLM-side kernels
+@pytest.mark.parametrize("name,dt", DTYPES)
+def test_fused_cross_entropy_matches_torch(dev, name, dt):
+    """cambrian_llama.py:409-422: logits.float() -> shift -> CrossEntropyLoss(ignore_index=-100), forward value and
+    d loss / d logits, against torch on the same (dtype-rounded) logits."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(21)
+    B, S, V = 3, 37, 1000
+    logits = (_rand(g, B, S, V) * 3).to(dt)
+    labels = torch.randint(0, V, (B, S), generator=g)
+    labels[:, :5] = -100
+    labels[1, 20:25] = -100
+    ref_in = logits.float().clone().requires_grad_()
+    ref = F.cross_entropy(ref_in[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100)
+    (ref * 1.7).backward()
+    x = logits.detach().to(dev).requires_grad_()
+    shift = torch.full_like(labels, -100)
+    shift[:, :-1] = labels[:, 1:]
+    for inplace in (False, True):
+        xin = x.detach().clone().requires_grad_()
+        y = xin * 1.0  # non-leaf, so the in-place backward may overwrite it
+        loss = ops.cross_entropy(y.view(B * S, V), shift.view(-1).to(dev), -100, inplace=inplace)
+        assert abs(loss.item() - ref.item()) < (1e-5 if name == "fp32" else 1e-4) * max(1.0, abs(ref.item()))
+        (loss * 1.7).backward()
+        assert rel_err(xin.grad.view(B, S, V), ref_in.grad) < (TOL[name] if name == "fp32" else 1e-2)
+        assert torch.count_nonzero(xin.grad[:, -1]) == 0  # last position of every sequence is never scored
+
+
+@pytest.mark.parametrize("name,dt", DTYPES)
+def test_swiglu_fwd_bwd(dev, name, dt):
+    ops, L = _ops()
+    g_ = torch.Generator().manual_seed(22)
+    a, b = (_rand(g_, 5, 33, 64) * 2).to(dt), _rand(g_, 5, 33, 64).to(dt)
+    ar, br = a.float().clone().requires_grad_(), b.float().clone().requires_grad_()
+    ref = F.silu(ar) * br
+    w = _rand(g_, 5, 33, 64)
+    (ref * w).sum().backward()
+    ad, bd = a.detach().to(dev).requires_grad_(), b.detach().to(dev).requires_grad_()
+    out = ops.swiglu(ad, bd)
+    (out.float() * w.to(dev)).sum().backward()
+    tol = TOL[name]
+    assert rel_err(out, ref) < tol
+    assert rel_err(ad.grad, ar.grad) < tol
+    assert rel_err(bd.grad, br.grad) < tol

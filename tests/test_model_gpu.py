@@ -114,11 +114,13 @@ def _oracle_run(model, cfg, towers, batch):
     return loss, logits, p
 
 
+@pytest.mark.parametrize("fused_loss", [False, True])
 @pytest.mark.parametrize("name,dt,tol_logits,tol_grad", [("fp32", torch.float32, 1e-3, 5e-3),
                                                           ("bf16", torch.bfloat16, 5e-2, 1.5e-1)])
-def test_end_to_end_logits_loss_and_gradients(dev, monkeypatch, name, dt, tol_logits, tol_grad):
+def test_end_to_end_logits_loss_and_gradients(dev, monkeypatch, name, dt, tol_logits, tol_grad, fused_loss):
     from cambrian_amd.train.data_layout import synthetic_batch
     model, cfg, towers = _build(dev, dt, monkeypatch)
+    cfg.fused_loss = fused_loss  # fused shifted CE over compute-dtype logits (bench.py) vs the reference's fp32 path
     batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
                             image_res=[56, 64], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
     ref_loss, ref_logits, p = _oracle_run(model, cfg, towers, batch)
@@ -129,9 +131,9 @@ def test_end_to_end_logits_loss_and_gradients(dev, monkeypatch, name, dt, tol_lo
                 images=[i.to(dev, dt) for i in batch["images"]],
                 image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
                 image_sizes=batch["image_sizes"])
-    out.loss.backward()
-    e = rel_err(out.logits, ref_logits)
+    e = rel_err(out.logits, ref_logits)  # before backward(): the fused loss turns the logits buffer into dlogits
     assert e < tol_logits, f"logits rel err {e}"
+    out.loss.backward()
     assert abs(out.loss.item() - ref_loss.item()) < tol_logits * max(1.0, abs(ref_loss.item()))
     worst = ("", 0.0)
     n_checked = 0
