@@ -118,6 +118,54 @@ __global__ void __launch_bounds__(256) swiglu_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// Fused QKV hand-off of a decoder layer: packed projection output [B*S, (nh + 2*nkv) * Dh] (q heads | k heads |
+// v heads per token) <-> the three token-major tensors q [B,S,nh,Dh], k / v [B,S,nkv,Dh] (the attention takes their
+// transposed views, so its output comes back token-major and the o_proj input needs no copy),
+// with RoPE (rotate-half, fp32 tables) applied to q and k on the way.  MERGE = backward: (dq, dk, dv) -> d(packed)
+// with the transposed rotation.  One workgroup per token; a head's Dh elements move as 16-byte vectors.
+template <typename T, bool MERGE>
+__global__ void __launch_bounds__(256) qkv_rope_kernel(T* __restrict__ packed, const float* __restrict__ cos_t,
+                                                       const float* __restrict__ sin_t, int64_t ntok, int S, int nh, int nkv,
+                                                       int Dh, T* __restrict__ q, T* __restrict__ k, T* __restrict__ v) {
+  const int half = Dh >> 1, gph = half >> 3;
+  const int H = nh + 2 * nkv;
+  const int items = H * gph;
+  for (int64_t tok = blockIdx.x; tok < ntok; tok += gridDim.x) {
+    T* pr = packed + tok * (int64_t)H * Dh;
+    const float* ct = cos_t + tok * half;
+    const float* st = sin_t + tok * half;
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+      const int h = it / gph, gi = it - h * gph;
+      T* hp;  // this token's row of head h in its head-major tensor
+      bool rot = true;
+      if (h < nh) hp = q + (tok * nh + h) * Dh;
+      else if (h < nh + nkv) hp = k + (tok * nkv + (h - nh)) * Dh;
+      else { hp = v + (tok * nkv + (h - nh - nkv)) * Dh; rot = false; }
+      T* src = MERGE ? hp : pr + h * Dh;
+      T* dst = MERGE ? pr + h * Dh : hp;
+      float a[8], bb[8];
+      Vec8<T>::load(src + gi * 8, a);
+      Vec8<T>::load(src + half + gi * 8, bb);
+      if (rot) {
+        float c[8], sn[8], oa[8], ob[8];
+        load8f(ct + gi * 8, c);
+        load8f(st + gi * 8, sn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float s_ = MERGE ? -sn[e] : sn[e];
+          oa[e] = a[e] * c[e] - bb[e] * s_;
+          ob[e] = bb[e] * c[e] + a[e] * s_;
+        }
+        Vec8<T>::store(dst + gi * 8, oa);
+        Vec8<T>::store(dst + half + gi * 8, ob);
+      } else {
+        Vec8<T>::store(dst + gi * 8, a);
+        Vec8<T>::store(dst + half + gi * 8, bb);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int cmb_cross_entropy_fwd(int dtype, const void* logits, int64_t rows, int64_t V, int64_t ld,
@@ -171,6 +219,25 @@ extern "C" int cmb_swiglu_bwd(int dtype, const void* dh, int64_t lddh, const voi
                        (const float*)g, ldg, (const float*)u, ldu, rows, (int)D, (float*)dg, lddg, (float*)du, lddu);
   else
     return CMB_ERR_BAD_ARG;
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_qkv_rope(int dtype, int32_t merge, void* packed, const float* cos_t, const float* sin_t, int64_t B,
+                            int64_t S, int32_t nh, int32_t nkv, int32_t Dh, void* q, void* k, void* v, void* stream) {
+  if (!packed || !cos_t || !sin_t || !q || !k || !v || B < 0 || S <= 0 || nh <= 0 || nkv <= 0 || Dh <= 0 || (Dh & 15))
+    return CMB_ERR_BAD_ARG;
+  if (B == 0) return CMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t ntok = B * S;
+  const int64_t blocks = ntok > 65535 ? 65535 : ntok;
+#define QKV(T, M)                                                                                                  \
+  hipLaunchKernelGGL((qkv_rope_kernel<T, M>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)packed, cos_t, sin_t, ntok, \
+                     (int)S, nh, nkv, Dh, (T*)q, (T*)k, (T*)v)
+  if (dtype == CMB_BF16) { if (merge) QKV(bf16_t, true); else QKV(bf16_t, false); }
+  else if (dtype == CMB_F32) { if (merge) QKV(float, true); else QKV(float, false); }
+  else return CMB_ERR_BAD_ARG;
+#undef QKV
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

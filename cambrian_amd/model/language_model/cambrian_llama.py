@@ -55,6 +55,23 @@ class HipRMSNorm(nn.Module):
         return ops.rmsnorm(x, self.weight, self.variance_epsilon)
 
 
+def _fused_frozen_weight(owner: nn.Module, key: str, mods) -> Optional[torch.Tensor]:
+    """[W_0; W_1; ...] of several bias-free nn.Linear whose weights are FROZEN (the pre-training stage freezes the
+    whole LLM, train_fsdp.py:1677-1685), cached on ``owner`` and rebuilt when a weight moves or changes.  One GEMM with
+    N = sum(N_i) then replaces len(mods) GEMMs forward and, in the backward, len(mods) dX GEMMs plus the adds that
+    accumulate them.  Trainable or biased projections return None (callers keep the separate-GEMM path); parameter
+    names / state_dict keys stay HF's (q_proj.weight, ...)."""
+    ws = [m.weight for m in mods]
+    if any(w.requires_grad for w in ws) or any(m.bias is not None for m in mods):
+        return None
+    tag = tuple((w.data_ptr(), w._version, w.dtype) for w in ws)
+    cached = owner.__dict__.get(key)
+    if cached is None or cached[0] != tag:
+        cached = (tag, torch.cat([w.detach() for w in ws], dim=0).contiguous())
+        owner.__dict__[key] = cached
+    return cached[1]
+
+
 class LlamaMLP(nn.Module):
     def __init__(self, cfg, device, dtype):
         super().__init__()
@@ -64,6 +81,9 @@ class LlamaMLP(nn.Module):
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, **kw)
 
     def forward(self, x):
+        w_gu = _fused_frozen_weight(self, "_w_gate_up", (self.gate_proj, self.up_proj))
+        if w_gu is not None and x.is_cuda:
+            return self.down_proj(ops.swiglu_packed(F.linear(x, w_gu)))
         return self.down_proj(ops.swiglu(self.gate_proj(x), self.up_proj(x)))
 
 
@@ -80,6 +100,12 @@ class LlamaAttention(nn.Module):
 
     def forward(self, x, cos, sin, attn_mask):
         B, S, _ = x.shape
+        w_qkv = _fused_frozen_weight(self, "_w_qkv", (self.q_proj, self.k_proj, self.v_proj))
+        if w_qkv is not None and x.is_cuda:
+            q, k, v = ops.qkv_rope(F.linear(x, w_qkv), cos, sin, self.nh, self.nkv, self.hd)
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
+                                               enable_gqa=self.nkv != self.nh)
+            return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
         q = ops.rope(self.q_proj(x).view(B * S, self.nh, self.hd), cos, sin).view(B, S, self.nh, self.hd).transpose(1, 2)
         k = ops.rope(self.k_proj(x).view(B * S, self.nkv, self.hd), cos, sin).view(B, S, self.nkv, self.hd).transpose(1, 2)
         v = self.v_proj(x).view(B, S, self.nkv, self.hd).transpose(1, 2)

@@ -807,3 +807,86 @@ class SwiGLUFn(torch.autograd.Function):
 
 def swiglu(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     return SwiGLUFn.apply(g, u)
+
+
+class QkvRopeFn(torch.autograd.Function):
+    """packed QKV projection [B,S,(nh+2nkv)*Dh] -> q [B,nh,S,Dh], k, v [B,nkv,S,Dh] (transposed VIEWS of token-major
+    buffers) with RoPE on q and k, one kernel;
+    the backward merges (dq, dk, dv) into one d(packed) with the inverse rotation (no slice-backward zero fills)."""
+
+    @staticmethod
+    def forward(ctx, packed, cos, sin, nh: int, nkv: int, hd: int):
+        L.require_gpu(packed, cos, sin)
+        B, S, W = packed.shape
+        if W != (nh + 2 * nkv) * hd or not packed.is_contiguous():
+            raise L.CambrianAmdError("packed QKV must be contiguous [B,S,(nh+2*nkv)*hd]")
+        dt, dev = packed.dtype, packed.device
+        q = torch.empty((B, S, nh, hd), dtype=dt, device=dev)
+        k = torch.empty((B, S, nkv, hd), dtype=dt, device=dev)
+        v = torch.empty((B, S, nkv, hd), dtype=dt, device=dev)
+        rc = L.load().cmb_qkv_rope(L.dtype_code(dt), 0, packed.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, S, nh, nkv, hd,
+                                   q.data_ptr(), k.data_ptr(), v.data_ptr(), L.stream_ptr(dev))
+        L.check(rc, "cmb_qkv_rope(split)")
+        ctx.save_for_backward(cos, sin)
+        ctx.cfg = (B, S, nh, nkv, hd)
+        return q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)  # [B,H,S,hd] views of token-major storage
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        cos, sin = ctx.saved_tensors
+        B, S, nh, nkv, hd = ctx.cfg
+        # token-major storage; free when the attention backward returns grads laid out like its inputs
+        dq, dk, dv = (t.transpose(1, 2).contiguous() for t in (dq, dk, dv))
+        dp = torch.empty((B, S, (nh + 2 * nkv) * hd), dtype=dq.dtype, device=dq.device)
+        rc = L.load().cmb_qkv_rope(L.dtype_code(dq.dtype), 1, dp.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, S, nh, nkv, hd,
+                                   dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), L.stream_ptr(dq.device))
+        L.check(rc, "cmb_qkv_rope(merge)")
+        return dp, None, None, None, None, None
+
+
+def qkv_rope(packed, cos, sin, nh: int, nkv: int, hd: int):
+    return QkvRopeFn.apply(packed, cos, sin, nh, nkv, hd)
+
+
+class SwiGLUPackedFn(torch.autograd.Function):
+    """h = silu(gu[:, :I]) * gu[:, I:] for the packed output of a fused gate|up projection [T, 2I]; the backward
+    writes both halves of d(gu) straight into one [T, 2I] buffer."""
+
+    @staticmethod
+    def forward(ctx, gu):
+        L.require_gpu(gu)
+        shape = gu.shape
+        I2 = shape[-1]
+        I = I2 // 2
+        g2 = gu.reshape(-1, I2)
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        rows = g2.shape[0]
+        h = torch.empty((rows, I), dtype=gu.dtype, device=gu.device)
+        es = g2.element_size()
+        rc = L.load().cmb_act_mul(L.dtype_code(gu.dtype), L.ACT_SILU, g2.data_ptr(), I2, g2.data_ptr() + I * es, I2,
+                                  rows, I, h.data_ptr(), I, L.stream_ptr(gu.device))
+        L.check(rc, "cmb_act_mul(silu, packed)")
+        ctx.save_for_backward(g2)
+        ctx.shape = shape
+        return h.view(*shape[:-1], I)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (g2,) = ctx.saved_tensors
+        rows, I2 = g2.shape
+        I = I2 // 2
+        dh2 = dh.reshape(rows, I)
+        if dh2.stride(1) != 1:
+            dh2 = dh2.contiguous()
+        dgu = torch.empty((rows, I2), dtype=g2.dtype, device=g2.device)
+        es = g2.element_size()
+        rc = L.load().cmb_swiglu_bwd(L.dtype_code(g2.dtype), dh2.data_ptr(), dh2.stride(0), g2.data_ptr(), I2,
+                                     g2.data_ptr() + I * es, I2, rows, I, dgu.data_ptr(), I2, dgu.data_ptr() + I * es, I2,
+                                     L.stream_ptr(g2.device))
+        L.check(rc, "cmb_swiglu_bwd(packed)")
+        return dgu.view(ctx.shape)
+
+
+def swiglu_packed(gu: torch.Tensor) -> torch.Tensor:
+    return SwiGLUPackedFn.apply(gu)

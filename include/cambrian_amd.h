@@ -270,6 +270,12 @@ int cmb_cross_entropy_fwd(int dtype, const void* logits, int64_t rows, int64_t V
 int cmb_cross_entropy_bwd(int dtype, const void* logits, int64_t rows, int64_t V, int64_t ld,
                           const int64_t* labels, int64_t ignore_index, const float* lse, const float* scale,
                           void* dlogits, int64_t ldd, void* stream);
+/* Fused QKV hand-off of a decoder layer: packed [B*S, (nh + 2*nkv)*Dh] (q heads | k heads | v heads per token)
+ * -> q [B,S,nh,Dh], k [B,S,nkv,Dh], v [B,S,nkv,Dh] (token-major) with RoPE (tables of cmb_rope_table) on q and k; merge != 0 is the
+ * backward: (dq, dk, dv) -> d(packed) with the transposed rotation.  Replaces the q/k/v views, two rotary passes and
+ * the transposes in front of the attention (HF LlamaAttention reached from cambrian_llama.py:157-166). Dh % 16 == 0. */
+int cmb_qkv_rope(int dtype, int32_t merge, void* packed, const float* cos_t, const float* sin_t, int64_t B, int64_t S,
+                 int32_t nh, int32_t nkv, int32_t Dh, void* q, void* k, void* v, void* stream);
 /* Backward of h = silu(g) * u (Llama MLP gate; forward is cmb_act_mul with CMB_ACT_SILU):
  * dg = dh * u * silu'(g), du = dh * silu(g); all [rows, D] with row strides. */
 int cmb_swiglu_bwd(int dtype, const void* dh, int64_t lddh, const void* g, int64_t ldg, const void* u, int64_t ldu,

@@ -448,3 +448,54 @@ def test_swiglu_fwd_bwd(dev, name, dt):
     assert rel_err(out, ref) < tol
     assert rel_err(ad.grad, ar.grad) < tol
     assert rel_err(bd.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("name,dt", DTYPES)
+def test_qkv_rope_split_and_merge(dev, name, dt):
+    """Packed QKV -> (q, k, v) head-major with RoPE == separate views + rotate-half RoPE (phi3/modeling_phi3.py:257-281)
+    + transposes; the backward is checked through autograd against the same torch graph."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(31)
+    B, S, nh, nkv, hd = 2, 19, 4, 2, 32
+    packed = _rand(g, B, S, (nh + 2 * nkv) * hd).to(dt)
+    pos = torch.randint(0, 500, (B, S), generator=g)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = pos.reshape(-1, 1).float() * inv[None]
+    cos_r, sin_r = torch.cos(ang), torch.sin(ang)                     # [B*S, hd/2]
+
+    def rot(x):                                                        # x [B,S,H,hd]
+        x1, x2 = x[..., : hd // 2], x[..., hd // 2:]
+        c, s_ = cos_r.view(B, S, 1, hd // 2), sin_r.view(B, S, 1, hd // 2)
+        return torch.cat([x1 * c - x2 * s_, x2 * c + x1 * s_], dim=-1)
+
+    pr = packed.float().clone().requires_grad_()
+    qr = rot(pr[..., : nh * hd].view(B, S, nh, hd)).transpose(1, 2)
+    kr = rot(pr[..., nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)).transpose(1, 2)
+    vr = pr[..., (nh + nkv) * hd:].view(B, S, nkv, hd).transpose(1, 2)
+    wq, wk, wv = _rand(g, B, nh, S, hd), _rand(g, B, nkv, S, hd), _rand(g, B, nkv, S, hd)
+    ((qr * wq).sum() + (kr * wk).sum() + (vr * wv).sum()).backward()
+
+    cos, sin = ops.rope_table(pos.to(dev), hd, 10000.0)
+    pd = packed.detach().to(dev).requires_grad_()
+    q, k, v = ops.qkv_rope(pd, cos, sin, nh, nkv, hd)
+    assert q.shape == (B, nh, S, hd) and k.shape == (B, nkv, S, hd) and v.transpose(1, 2).is_contiguous()
+    ((q.float() * wq.to(dev)).sum() + (k.float() * wk.to(dev)).sum() + (v.float() * wv.to(dev)).sum()).backward()
+    tol = TOL[name] * (5 if name == "fp32" else 1)
+    assert rel_err(q, qr) < tol and rel_err(k, kr) < tol
+    assert torch.equal(v.cpu().float(), vr.detach().to(dt).float())    # v is a pure copy: bit-exact
+    assert rel_err(pd.grad, pr.grad) < tol
+
+
+@pytest.mark.parametrize("name,dt", DTYPES)
+def test_swiglu_packed(dev, name, dt):
+    ops, L = _ops()
+    g_ = torch.Generator().manual_seed(23)
+    gu = (_rand(g_, 3, 17, 128) * 2).to(dt)
+    r = gu.float().clone().requires_grad_()
+    ref = F.silu(r[..., :64]) * r[..., 64:]
+    w = _rand(g_, 3, 17, 64)
+    (ref * w).sum().backward()
+    x = gu.detach().to(dev).requires_grad_()
+    out = ops.swiglu_packed(x)
+    (out.float() * w.to(dev)).sum().backward()
+    assert rel_err(out, ref) < TOL[name] and rel_err(x.grad, r.grad) < TOL[name]
