@@ -359,10 +359,13 @@ def test_patchify_and_conv_equivalence(dev, name, dt):
 
 
 @pytest.mark.parametrize("name,dt", DTYPES)
-def test_dwconv7x7(dev, name, dt):
+@pytest.mark.parametrize("B,Hh,Ww,C", [(2, 13, 10, 72),     # C % 64 != 0: direct kernel
+                                       (2, 13, 10, 128),    # LDS-tiled kernel, ragged tile edges in x and y
+                                       (1, 32, 48, 192),    # several full tiles
+                                       (3, 7, 5, 64)])      # image smaller than one tile
+def test_dwconv7x7(dev, name, dt, B, Hh, Ww, C):
     from cambrian_amd.model.multimodal_encoder import vit_ops
-    g = torch.Generator().manual_seed(37)
-    B, Hh, Ww, C = 2, 13, 10, 72
+    g = torch.Generator().manual_seed(37 + C + Hh)
     x = _rand(g, B, Hh, Ww, C).to(dt)
     w, b = _rand(g, C, 1, 7, 7, scale=0.1), _rand(g, C)
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, b, padding=3, groups=C).permute(0, 2, 3, 1)
