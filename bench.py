@@ -45,9 +45,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAMBRIAN_BENCH_BATCH", "8")),
-                    help="images per GPU per step (reference: per_device_train_batch_size 8)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAMBRIAN_BENCH_BATCH", "16")),
+                    help="images per GPU per step.  The reference runs per_device_train_batch_size 8 on 32 GB TPU-v4 cores "
+                         "(pretrain_cambrian_8b.sh:37); 16 uses 156 of the MI355X's 288 GB (no activation re-computation) and "
+                         "fills the chip better on the towers' mid-size GEMMs (+4 % images/s over 8; 32 = 278 GB, too close)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
+                    "config 4's partitioning) instead of all-reduce + replicated AdamW")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-report", type=str, default=None, help="write a per-shape table of the hot-path GEMM launches (JSON)")
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (marks the line INVALID)")
@@ -143,8 +147,12 @@ def main():
 
     model, cfg = build_model(dev, args.llm_layers)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
-    sync = GradSync(params)
+    if args.zero2:
+        from cambrian_amd.train.zero import Zero2AdamW
+        opt, sync = Zero2AdamW(params, lr=1e-4, weight_decay=0.0), None
+    else:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
+        sync = GradSync(params)
     B = args.batch
     batch = synthetic_batch(B, seed=1234 + rank)
     kw = dict(input_ids=batch["input_ids"].to(dev), labels=batch["labels"].to(dev),
@@ -157,7 +165,8 @@ def main():
     def step():
         out = model(**kw)
         out.loss.backward()
-        sync.finish()
+        if sync is not None:
+            sync.finish()
         opt.step()
         opt.zero_grad(set_to_none=True)
         return out.loss
@@ -195,7 +204,8 @@ def main():
                                    "Llama-3-8B, 576 visual + 24 newline tokens in a 2048-token sequence, pre-training "
                                    "stage (SVA+projectors train, LLM+towers frozen), fwd+bwd+all-reduce+AdamW",
                        "images_per_gpu": B, "global_batch": B * world, "seq_len": 2048,
-                       "parallelism": f"dp{world}", "loss": float(loss.item())},
+                       "parallelism": f"dp{world}" + ("+zero2" if args.zero2 else ""), "loss": float(loss.item()),
+                       "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
         }
         if args.llm_layers is not None:
             line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"

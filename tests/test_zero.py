@@ -1,0 +1,101 @@
+"""CPU, world_size 2, gloo: ZeRO-2 AdamW (cambrian_amd/train/zero.py) — reduce-scattered gradient shards, sharded Adam
+state, all-gathered parameters — leaves every rank with exactly the parameters an unsharded AdamW produces from the
+rank-averaged gradients, over several steps, including a parameter that never receives a gradient."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 33), torch.nn.GELU(), torch.nn.Linear(33, 32), torch.nn.LayerNorm(32),
+                               torch.nn.Linear(32, 5))
+
+
+def _data(world, step):
+    return [torch.randn(8, 16, generator=torch.Generator().manual_seed(100 * step + k)) for k in range(world)]
+
+
+def _reference(world, steps, lr, wd):
+    m = _model()
+    unused = torch.nn.Parameter(torch.ones(7))
+    params = list(m.parameters()) + [unused]
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=wd)
+    for step in range(steps):
+        grads = None
+        for k in range(world):
+            for p in params:
+                p.grad = None
+            m(_data(world, step)[k]).pow(2).mean().backward()
+            g = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in params]
+            grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+        for p, g in zip(params, grads):
+            p.grad = g / world
+        opt.step()
+    return [p.detach().clone() for p in params]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cambrian_amd.train.dp import init_distributed
+    from cambrian_amd.train.zero import Zero2AdamW
+    init_distributed("gloo")
+    m = _model()
+    unused = torch.nn.Parameter(torch.ones(7))
+    params = list(m.parameters()) + [unused]
+    opt = Zero2AdamW(params, lr=1e-2, weight_decay=0.1, bucket_mb=0.002)   # tiny buckets -> several collectives
+    assert len(opt.buckets) > 2
+    full = sum(p.numel() for p in params) * 8
+    assert opt.state_bytes() < 0.6 * full                                    # Adam moments are sharded
+    steps = 3
+    for step in range(steps):
+        m(_data(world, step)[rank]).pow(2).mean().backward()
+        opt.step()
+        opt.zero_grad()
+    want = _reference(world, steps, 1e-2, 0.1)
+    ok = all(torch.allclose(p.detach(), w, atol=1e-6, rtol=1e-5) for p, w in zip(params, want))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero2_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_zero2_single_process_equals_adamw():
+    from cambrian_amd.train.zero import Zero2AdamW
+    m = _model()
+    params = list(m.parameters())
+    opt = Zero2AdamW(params, lr=1e-2, weight_decay=0.1)
+    for step in range(2):
+        m(_data(1, step)[0]).pow(2).mean().backward()
+        opt.step()
+        opt.zero_grad()
+    m2 = _model()
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-2, weight_decay=0.1)
+    for step in range(2):
+        o2.zero_grad()
+        m2(_data(1, step)[0]).pow(2).mean().backward()
+        o2.step()
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.allclose(a, b, atol=1e-7, rtol=1e-6)
