@@ -114,7 +114,12 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
     else:
         d.workspace, d.workspace_bytes = None, 0
     prof = GEMM_PROFILE
+    tile_used = 0
     if prof is not None:  # HIP events on the launch stream around this launch (bench.py roofline leg)
+        tile_used = L.load().cmb_gemm_tile(d.dtype, M, N, split_k, tile)
+        if GEMM_PROFILE_TILE and tile_used != GEMM_PROFILE_TILE:
+            prof = None  # only the dominant kernel is timed: every event pair costs the stream a barrier packet
+    if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = L.load().cmb_gemm(C.byref(d), L.stream_ptr(a.device))
@@ -122,13 +127,13 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, dt, split_k,
-                     L.load().cmb_gemm_tile(d.dtype, M, N, split_k, tile), (M, N, K, act, out.dtype == torch.float32)))
+        prof.append((e0, e1, 2.0 * M * N * K, dt, split_k, tile_used, (M, N, K, act, out.dtype == torch.float32)))
     return out
 
 
 # bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k, tile) per GEMM launch
 GEMM_PROFILE = None
+GEMM_PROFILE_TILE = 0  # 0 = time every GEMM launch; 128 / 256 = only launches of that tile configuration
 
 
 def k_transpose(x: torch.Tensor, r_pad: Optional[int] = None) -> torch.Tensor:
