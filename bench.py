@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
                     "config 4's partitioning) instead of all-reduce + replicated AdamW")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-tuned-llm-gemms", action="store_true", help="do not load the pre-tuned TunableOp table for the LLM's hipBLASLt GEMMs")
     ap.add_argument("--gemm-report", type=str, default=None, help="write a per-shape table of the hot-path GEMM launches (JSON)")
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (marks the line INVALID)")
     return ap.parse_args()
@@ -144,6 +145,8 @@ def main():
         dist.barrier()
     from cambrian_amd import ops
     from cambrian_amd.train.data_layout import synthetic_batch
+    from cambrian_amd.train.llm_gemm_tuning import load_tuned_llm_gemms
+    tuned = (not args.no_tuned_llm_gemms) and load_tuned_llm_gemms()
 
     model, cfg = build_model(dev, args.llm_layers)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -206,7 +209,8 @@ def main():
                                    "stage (SVA+projectors train, LLM+towers frozen), fwd+bwd+all-reduce+AdamW",
                        "images_per_gpu": B, "global_batch": B * world, "seq_len": 2048,
                        "parallelism": f"dp{world}" + ("+zero2" if args.zero2 else ""), "loss": float(loss.item()),
-                       "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
+                       "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                       "llm_gemm_solutions": "pre-tuned TunableOp table" if tuned else "PyTorch default heuristic"},
         }
         if args.llm_layers is not None:
             line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"

@@ -48,6 +48,38 @@ class SvaContext:
     side: int
 
 
+def unmask_attention_mask(mask, original_size):
+    """cambrian_arch.py:203-225 — zero the grid rows / columns that are padding of the squared (expand2square) image."""
+    original_w, original_h = original_size
+    cur_h, cur_w = mask.shape[1:3]
+    if original_w / original_h > cur_w / cur_h:
+        new_height = int(original_h * (cur_w / original_w))
+        padding = (cur_h - new_height) // 2
+        if padding > 0:
+            mask[:, :padding, :] = 0
+            mask[:, -padding:, :] = 0
+    else:
+        new_width = int(original_w * (cur_h / original_h))
+        padding = (cur_w - new_width) // 2
+        if padding > 0:
+            mask[:, :, :padding] = 0
+            mask[:, :, -padding:] = 0
+    return mask
+
+
+def unpad_image(tensor, original_size):
+    """cambrian_arch.py:228-256 — crop dims (1, 2) of a grid tensor back to the original aspect ratio."""
+    original_width, original_height = original_size
+    current_height, current_width = tensor.shape[1:3]
+    if original_width / original_height > current_width / current_height:
+        new_height = int(original_height * (current_width / original_width))
+        padding = (current_height - new_height) // 2
+        return tensor[:, padding:current_height - padding, :]
+    new_width = int(original_width * (current_height / original_height))
+    padding = (current_width - new_width) // 2
+    return tensor[:, :, padding:current_width - padding]
+
+
 def _sva_modules(owner: nn.Module, config, vision_tower_aux_list, hidden_size: int):
     """Shared by __init__ (config-driven, cambrian_arch.py:41-79) and initialize_vision_modules (:142-169)."""
     vh = config.vision_hidden_size
@@ -181,7 +213,33 @@ class CambrianMetaForCausalLM(ABC):
 
     def rearrange_vision_tower_features_inference(self, vision_tower_aux_feature_list, query_side_len, image_sizes,
                                                   unpad=False):
-        raise NotImplementedError("dynamic (eval/generate) path: SURVEY.md §8f N1, not part of the training hot path")
+        """cambrian_arch.py:289-330 (eval / generate branch): per-sample window-major KV lists and masks; with
+        ``unpad`` the query grid is cropped to the image's aspect ratio, so samples contribute different numbers of
+        queries.  Pure index work (views / copies), as in the reference."""
+        feats_out, masks_out = [], []
+        bs = vision_tower_aux_feature_list[0].shape[0]
+        for f in vision_tower_aux_feature_list:
+            side = int(f.shape[1] ** 0.5)
+            assert (side // query_side_len) * query_side_len == side
+            r = side // query_side_len
+            fl, ml = [], []
+            for b in range(bs):
+                m = torch.ones((1, side, side), dtype=torch.bool, device=f.device)
+                x = f[b].view(1, query_side_len, r, query_side_len, r, -1).permute(0, 1, 3, 2, 4, 5).contiguous()
+                if unpad:
+                    x = unpad_image(x, image_sizes[b])
+                x = x.flatten(0, 2).flatten(1, 2)
+                m = unmask_attention_mask(m, image_sizes[b])
+                m = m.view(1, query_side_len, r, query_side_len, r).permute(0, 1, 3, 2, 4).contiguous()
+                if unpad:
+                    m = unpad_image(m, image_sizes[b])
+                m = m.flatten(0, 2).flatten(1, 2)
+                m[m.sum(-1) == 0] = True
+                fl.append(x)
+                ml.append(m)
+            feats_out.append(torch.cat(fl, 0))
+            masks_out.append(torch.cat(ml, 0))
+        return feats_out, masks_out
 
     def encode_images(self, image_aux_list):
         towers = self.get_model().get_vision_tower_aux_list()
@@ -194,8 +252,9 @@ class CambrianMetaForCausalLM(ABC):
         towers = model.get_vision_tower_aux_list()
         if towers is None or images is None or input_ids.shape[1] == 1:  # cambrian_arch.py:346-347
             return input_ids, position_ids, attention_mask, past_key_values, None, labels, None, None, None, None
-        if not STATIC_PATH:
-            raise NotImplementedError("dynamic (eval/generate) path: SURVEY.md §8f N1")
+        if not STATIC_PATH or getattr(self, "_dynamic_path", False):
+            return self._prepare_inputs_dynamic(input_ids, position_ids, attention_mask, past_key_values, labels, images,
+                                                image_sizes)
         cfg = model.config
         if getattr(cfg, "tune_mm_mlp_adapter", False) and getattr(cfg, "mm_use_im_start_end", False):
             raise NotImplementedError  # cambrian_arch.py:454-455
@@ -252,6 +311,111 @@ class CambrianMetaForCausalLM(ABC):
         kv_final, m_final = self.rearrange_vision_tower_features_train(f3, image_aux_attention_masks_list, side)
         ctx_final = sva_ctx.ctx_b[:, None, None, :].expand(-1, side * side, 1, -1).flatten(0, 1)
         return None, position_ids, attention_mask, past_key_values, inputs_embeds, labels, kv_final, m_final, final_size, ctx_final
+
+    # ------------------------------------------------------------------------------------------
+    def _prepare_inputs_dynamic(self, input_ids, position_ids, attention_mask, past_key_values, labels, images, image_sizes):
+        """The eval / generate branch of prepare_inputs_labels_for_multimodal (``IS_XLA_AVAILABLE`` False in the reference;
+        here ``STATIC_PATH = False`` or ``generate()``): cambrian_arch.py:366-402 with rearrange_..._inference, :422-451
+        (per-sample unpad + newline; in-LLM KV lists with unpad=True), :492-609 (variable-length merge, padding).
+        Returns the reference's 10-tuple with window-major KV lists / bool masks / concatenated context rows; the SVA
+        layers then run through their reference calling convention (VisionCrossAttentionLayer.forward)."""
+        model = self.get_model()
+        cfg = model.config
+        if getattr(cfg, "tune_mm_mlp_adapter", False) and getattr(cfg, "mm_use_im_start_end", False):
+            raise NotImplementedError  # cambrian_arch.py:454-455
+        towers = model.get_vision_tower_aux_list()
+        bs = images[0].shape[0]
+        dtype = images[0].dtype
+        side = int(cfg.image_token_len ** 0.5)
+        feats_raw = self.encode_images(images)
+        kv_final = mask_final = ctx_final = None
+        if cfg.mm_projector_type == "sva":
+            feats = [getattr(model, f"mm_projector_aux_{i}")(feats_raw[i].to(dtype)).to(dtype) for i in range(len(towers))]
+            ctx_b = ops.token_mean(feats[0])                                           # [B, C] (:377)
+            ctx = ctx_b.view(bs, 1, 1, -1)
+            group_out = []
+            for g, query_num in enumerate(cfg.query_num_list):
+                qside = int(query_num ** 0.5)
+                q = model.vision_query[g].to(dtype).view(1, 1, 1, -1).expand(bs, query_num, -1, -1).flatten(0, 1)
+                ctx_g = ctx.expand(-1, query_num, 1, -1).flatten(0, 1)
+                kv, masks = self.rearrange_vision_tower_features_inference(feats, qside, image_sizes)
+                out = getattr(model, f"vision_sampler_{g}")(q.contiguous(), ctx_g.contiguous(), *kv, *masks)
+                out = out.view(bs, query_num, -1)
+                if qside != side:                                                      # :395-401
+                    out = out.permute(0, 2, 1).contiguous().view(bs, -1, qside, qside)
+                    out = torch.nn.functional.interpolate(out.float(), size=(side, side), mode="bilinear",
+                                                          align_corners=False).to(dtype)
+                    out = out.permute(0, 2, 3, 1).contiguous().flatten(1, 2)
+                group_out.append(out)
+            image_features = torch.cat(group_out, -1)
+            kv_final, mask_final = self.rearrange_vision_tower_features_inference(feats, side, image_sizes, unpad=True)
+        else:
+            image_features = torch.cat(feats_raw, -1).to(dtype)
+        image_features = model.mm_projector(image_features).to(dtype).view(bs, side, side, -1)   # :411, :424
+        vis, final_size, ctx_rows = [], [], []
+        for b in range(bs):                                                                      # :431-447
+            cur = unpad_image(image_features[b].unsqueeze(0), image_sizes[b])
+            h, w = cur.shape[1:3]
+            final_size.append((h, w))
+            nl = model.image_newline.to(cur.dtype).view(1, 1, 1, -1).expand(1, h, 1, -1)
+            vis.append(torch.cat((cur.reshape(1, h, w, -1), nl), dim=2).flatten(1, 2).squeeze(0))
+            if kv_final is not None:
+                ctx_rows.append(ctx[b].expand(h * w, 1, -1))
+        if kv_final is not None:
+            ctx_final = torch.cat(ctx_rows, 0)
+
+        # ---- variable-length merge (:492-609) ----
+        _labels, _position_ids, _attention_mask = labels, position_ids, attention_mask
+        att = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
+        if labels is None:
+            labels = torch.full_like(input_ids, IGNORE_INDEX)
+        embed = model.embed_tokens
+        new_embeds, new_labels = [], []
+        cur_image_idx = 0
+        for b in range(bs):
+            ids, lab = input_ids[b][att[b]], labels[b][att[b]]
+            idx = torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist()
+            if not idx:                                                                           # :519-526
+                new_embeds.append(embed(ids).to(vis[0].dtype))
+                new_labels.append(lab)
+                cur_image_idx += 1
+                continue
+            bounds = [-1] + idx + [ids.shape[0]]
+            pieces_e, pieces_l = [], []
+            for i in range(len(bounds) - 1):
+                seg = ids[bounds[i] + 1:bounds[i + 1]]
+                pieces_e.append(embed(seg).to(vis[0].dtype))
+                pieces_l.append(lab[bounds[i] + 1:bounds[i + 1]])
+                if i < len(idx):
+                    v = vis[cur_image_idx]
+                    cur_image_idx += 1
+                    pieces_e.append(v)
+                    pieces_l.append(torch.full((v.shape[0],), IGNORE_INDEX, device=lab.device, dtype=lab.dtype))
+            new_embeds.append(torch.cat(pieces_e))
+            new_labels.append(torch.cat(pieces_l))
+        max_model_len = getattr(cfg, "tokenizer_model_max_length", None)
+        if max_model_len is not None:
+            new_embeds = [x[:max_model_len] for x in new_embeds]
+            new_labels = [x[:max_model_len] for x in new_labels]
+        max_len = max(x.shape[0] for x in new_embeds)
+        dev = new_embeds[0].device
+        emb = torch.zeros((bs, max_len, new_embeds[0].shape[1]), dtype=new_embeds[0].dtype, device=dev)
+        lab_pad = torch.full((bs, max_len), IGNORE_INDEX, dtype=new_labels[0].dtype, device=dev)
+        att_pad = torch.zeros((bs, max_len), dtype=torch.bool, device=dev)
+        pos_pad = torch.zeros((bs, max_len), dtype=torch.long, device=dev)
+        left = getattr(cfg, "tokenizer_padding_side", "right") == "left"
+        for b, (e, l) in enumerate(zip(new_embeds, new_labels)):
+            n = e.shape[0]
+            sl = slice(max_len - n, max_len) if left else slice(0, n)
+            emb[b, sl] = e
+            if n > 0:
+                lab_pad[b, sl] = l
+                att_pad[b, sl] = True
+                pos_pad[b, sl] = torch.arange(n, device=dev)
+        out_labels = None if _labels is None else lab_pad
+        out_att = None if _attention_mask is None else att_pad.to(_attention_mask.dtype)
+        out_pos = None if _position_ids is None else pos_pad
+        return (None, out_pos, out_att, past_key_values, emb, out_labels, kv_final, mask_final, final_size, ctx_final)
 
     @staticmethod
     def _masks_u8(mask_list, bs: int, side: int, feats: Sequence[torch.Tensor]):

@@ -45,6 +45,13 @@ class CambrianConfig(LlamaConfig):
             self.rope_theta = float(rp.get("rope_theta", kwargs.get("rope_theta", 10000.0)))
 
 
+class SvaDynamic:
+    """In-LLM SVA inputs of the eval / generate branch: the reference-format lists of cambrian_arch.py:422-451."""
+
+    def __init__(self, feats, masks, final_size, ctx):
+        self.feats, self.masks, self.final_size, self.ctx = list(feats), list(masks), list(final_size), ctx
+
+
 class HipRMSNorm(nn.Module):
     def __init__(self, hidden_size, eps=1e-6, device=None, dtype=None):
         super().__init__()
@@ -98,20 +105,38 @@ class LlamaAttention(nn.Module):
         self.v_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, **kw)
         self.o_proj = nn.Linear(self.nh * self.hd, cfg.hidden_size, **kw)
 
-    def forward(self, x, cos, sin, attn_mask):
+    def forward(self, x, cos, sin, attn_mask, kv_out: Optional[list] = None):
+        """``kv_out``: if a list, (k, v) [B,nkv,S,hd] (post-RoPE) are appended — the prefill of ``generate()``."""
         B, S, _ = x.shape
         w_qkv = _fused_frozen_weight(self, "_w_qkv", (self.q_proj, self.k_proj, self.v_proj))
         if w_qkv is not None and x.is_cuda:
             q, k, v = ops.qkv_rope(F.linear(x, w_qkv), cos, sin, self.nh, self.nkv, self.hd)
+            if kv_out is not None:
+                kv_out.append((k, v))
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                                enable_gqa=self.nkv != self.nh)
             return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
         q = ops.rope(self.q_proj(x).view(B * S, self.nh, self.hd), cos, sin).view(B, S, self.nh, self.hd).transpose(1, 2)
         k = ops.rope(self.k_proj(x).view(B * S, self.nkv, self.hd), cos, sin).view(B, S, self.nkv, self.hd).transpose(1, 2)
         v = self.v_proj(x).view(B, S, self.nkv, self.hd).transpose(1, 2)
+        if kv_out is not None:
+            kv_out.append((k, v))
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                            enable_gqa=self.nkv != self.nh)
         return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
+
+    def decode(self, x, cos, sin, kcache, vcache, t: int, key_mask):
+        """One new token per sequence against the cache (decode steps never see the SVA hook: cambrian_llama.py:174,
+        ``prepare_inputs`` early-outs for length-1 inputs).  x [B,1,H]; k/v caches [B,nkv,Lmax,hd], slot t is filled here;
+        key_mask bool [B, t+1]."""
+        B = x.shape[0]
+        q = ops.rope(self.q_proj(x).view(B, self.nh, self.hd), cos, sin).view(B, 1, self.nh, self.hd).transpose(1, 2)
+        k = ops.rope(self.k_proj(x).view(B, self.nkv, self.hd), cos, sin)
+        kcache[:, :, t] = k
+        vcache[:, :, t] = self.v_proj(x).view(B, self.nkv, self.hd)
+        o = F.scaled_dot_product_attention(q, kcache[:, :, :t + 1], vcache[:, :, :t + 1], attn_mask=key_mask[:, None, None, :],
+                                           enable_gqa=self.nkv != self.nh)
+        return self.o_proj(o.transpose(1, 2).reshape(B, 1, self.nh * self.hd))
 
 
 class LlamaDecoderLayer(nn.Module):
@@ -122,8 +147,12 @@ class LlamaDecoderLayer(nn.Module):
         self.input_layernorm = HipRMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device, dtype)
         self.post_attention_layernorm = HipRMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device, dtype)
 
-    def forward(self, x, cos, sin, attn_mask):
-        x = x + self.self_attn(self.input_layernorm(x), cos, sin, attn_mask)
+    def forward(self, x, cos, sin, attn_mask, kv_out: Optional[list] = None):
+        x = x + self.self_attn(self.input_layernorm(x), cos, sin, attn_mask, kv_out)
+        return x + self.mlp(self.post_attention_layernorm(x))
+
+    def decode(self, x, cos, sin, kcache, vcache, t, key_mask):
+        x = x + self.self_attn.decode(self.input_layernorm(x), cos, sin, kcache, vcache, t, key_mask)
         return x + self.mlp(self.post_attention_layernorm(x))
 
 
@@ -157,7 +186,7 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
             _BackboneShim.attach(self, config)
 
     def forward(self, inputs_embeds: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
-                attention_mask: Optional[torch.Tensor] = None, sva: Optional[SvaContext] = None) -> torch.Tensor:
+                attention_mask: Optional[torch.Tensor] = None, sva=None, kv_out: Optional[list] = None) -> torch.Tensor:
         cfg = self.config
         B, S, H = inputs_embeds.shape
         dev = inputs_embeds.device
@@ -177,10 +206,33 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
             start, stride = cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers
             hook_layers = {start + k * stride: k for k in range(len(self.vision_sampler_layers))}  # :170-172
         for i, layer in enumerate(self.layers):
-            hidden = layer(hidden, cos, sin, attn_mask)
+            hidden = layer(hidden, cos, sin, attn_mask, kv_out)
             if i in hook_layers:
-                hidden = self._sva_hook(hidden, hook_layers[i], sva)
+                if isinstance(sva, SvaDynamic):
+                    hidden = self._sva_hook_dynamic(hidden, hook_layers[i], sva)
+                else:
+                    hidden = self._sva_hook(hidden, hook_layers[i], sva)
         return self.norm(hidden)
+
+    def _sva_hook_dynamic(self, hidden: torch.Tensor, k: int, sva: "SvaDynamic") -> torch.Tensor:
+        """cambrian_llama.py:209-253 (eval branch): every sample has its own cur_h x (cur_w + 1) block of latent
+        queries + newline column starting at ``image_position``; the queries of all samples go through the sampler layer
+        as one [sum h*w, 1, H] batch (KV lists / masks / context rows were concatenated the same way by
+        rearrange_vision_tower_features_inference(unpad=True)) and are written back; newline rows stay."""
+        p0 = self.config.image_position
+        rows, nums = [], []
+        for b, (h, w) in enumerate(sva.final_size):
+            blk = hidden[b, p0:p0 + h * (w + 1)].view(h, w + 1, -1)
+            rows.append(blk[:, :w].reshape(h * w, 1, -1))
+            nums.append(h * w)
+        q = torch.cat(rows, 0)
+        feats = [f if f.dtype == q.dtype else f.to(q.dtype) for f in sva.feats]      # :186 (same cast in both branches)
+        out = self.vision_sampler_layers[k](q, sva.ctx.to(q.dtype), *feats, *sva.masks)
+        hidden = hidden.clone()
+        for b, ob in enumerate(torch.split(out, nums, 0)):
+            h, w = sva.final_size[b]
+            hidden[b, p0:p0 + h * (w + 1)].view(h, w + 1, -1)[:, :w] = ob.view(h, w, -1)
+        return hidden
 
     def _sva_hook(self, hidden: torch.Tensor, k: int, sva: SvaContext) -> torch.Tensor:
         """cambrian_llama.py:177-207 (static branch)."""
@@ -234,15 +286,17 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
                 image_aux_attention_masks_list=None, image_sizes=None, return_dict=None, cache_position=None):
-        sva = None
+        sva = _masks = _final_size = _ctx = None
         if inputs_embeds is None:  # cambrian_llama.py:315-336
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels, sva, _masks, _final_size,
              _ctx) = self.prepare_inputs_labels_for_multimodal(input_ids, position_ids, attention_mask, past_key_values,
                                                                labels, images, image_aux_attention_masks_list, image_sizes)
             if inputs_embeds is None:  # text-only early-out (cambrian_arch.py:346-347)
                 inputs_embeds = self.model.embed_tokens(input_ids)
-        if sva is not None and not isinstance(sva, SvaContext):
-            raise TypeError("this decoder consumes the fused SvaContext (config.sva_fused = True)")
+        if isinstance(sva, (list, tuple)):
+            # reference-format lists (eval branch, or sva_fused = False): window-major KV, bool masks, per-sample (h, w),
+            # one context row per query — consumed by the general per-sample hook (cambrian_llama.py:209-253)
+            sva = SvaDynamic(sva, _masks, _final_size, _ctx)
         hidden = self.model(inputs_embeds.to(self.model.llm_dtype), position_ids, attention_mask, sva)
         logits = self.lm_head(hidden)                                                # :402-408
         loss = None
@@ -265,6 +319,74 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
         if CausalLMOutputWithPast is not None:
             return CausalLMOutputWithPast(loss=loss, logits=logits)
         return {"loss": loss, "logits": logits}
+
+
+def _generate(self, inputs=None, images=None, image_sizes=None, max_new_tokens: int = 16, do_sample: bool = False,
+              temperature: float = 1.0, eos_token_id=None, attention_mask=None, position_ids=None, **_unused):
+    """cambrian_llama.py:437-483: ``generate(input_ids, images=, image_sizes=)`` of the eval harness
+    (eval/eval/*/…_eval.py).  Prefill = the eval branch of prepare_inputs_labels_for_multimodal + the decoder with the
+    per-sample in-LLM SVA hook, K/V of every layer kept; decode steps = one token against the cache, no hook
+    (cambrian_llama.py:174).  Greedy or temperature sampling; returns the NEW token ids [B, <= max_new_tokens]
+    (like HF generate() called with inputs_embeds).  The reference inherits the loop from HF GenerationMixin."""
+    with torch.no_grad():
+        model = self.model
+        if images is not None:
+            self._dynamic_path = True
+            try:
+                (_, position_ids, attention_mask, _, inputs_embeds, _, kv, masks, final_size, ctx) = \
+                    self.prepare_inputs_labels_for_multimodal(inputs, position_ids, attention_mask, None, None, images,
+                                                              image_sizes=image_sizes)
+            finally:
+                self._dynamic_path = False
+            sva = None if kv is None else SvaDynamic(kv, masks, final_size, ctx)
+        else:
+            inputs_embeds, sva = model.embed_tokens(inputs), None
+        B, L, _ = inputs_embeds.shape
+        dev = inputs_embeds.device
+        valid = torch.ones(B, L, dtype=torch.bool, device=dev) if attention_mask is None else attention_mask.bool()
+        pos = (valid.long().cumsum(1) - 1).clamp_min(0) if position_ids is None else position_ids
+        kv_out: list = []
+        hidden = model(inputs_embeds.to(model.llm_dtype), pos, attention_mask, sva, kv_out=kv_out)
+        last = valid.long().sum(1) - 1                                              # last real token of every row
+        if not bool((valid[:, 1:] <= valid[:, :-1]).all()):
+            last = torch.full_like(last, L - 1)                                      # left padding: the last column
+        logits = self.lm_head(hidden[torch.arange(B, device=dev), last]).float()
+        nh_kv, hd = model.layers[0].self_attn.nkv, model.layers[0].self_attn.hd
+        Lmax = L + max_new_tokens
+        caches = []
+        for k, v in kv_out:
+            kc = torch.zeros(B, nh_kv, Lmax, hd, dtype=k.dtype, device=dev)
+            vc = torch.zeros_like(kc)
+            kc[:, :, :L], vc[:, :, :L] = k, v
+            caches.append((kc, vc))
+        key_mask = torch.zeros(B, Lmax, dtype=torch.bool, device=dev)
+        key_mask[:, :L] = valid
+        n_tok = valid.long().sum(1)
+        out_ids = []
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        theta = float(getattr(self.config, "rope_theta", 10000.0))
+        for step in range(max_new_tokens):
+            if do_sample and temperature > 0:
+                nxt = torch.multinomial(torch.softmax(logits / temperature, -1), 1)[:, 0]
+            else:
+                nxt = logits.argmax(-1)
+            if eos_token_id is not None:
+                nxt = torch.where(done, torch.full_like(nxt, eos_token_id), nxt)
+                done = done | (nxt == eos_token_id)
+            out_ids.append(nxt)
+            if step + 1 == max_new_tokens or (eos_token_id is not None and bool(done.all())):
+                break
+            t = L + step
+            key_mask[:, t] = True
+            cos, sin = ops.rope_table((n_tok + step)[:, None], hd, theta)
+            x = model.embed_tokens(nxt)[:, None, :].to(model.llm_dtype)
+            for layer, (kc, vc) in zip(model.layers, caches):
+                x = layer.decode(x, cos, sin, kc, vc, t, key_mask[:, :t + 1])
+            logits = self.lm_head(model.norm(x)[:, 0]).float()
+        return torch.stack(out_ids, 1)
+
+
+CambrianLlamaForCausalLM.generate = _generate
 
 
 def llama3_8b_config(**overrides) -> CambrianConfig:

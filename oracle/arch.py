@@ -168,3 +168,128 @@ def prepare_multimodal_data(input_ids, labels, attention_mask, image_sizes, imag
         out_pos.append(torch.cat(c_pos)[:max_length])
     return (torch.stack(out_ids), torch.stack(out_lab), torch.stack(out_att), torch.stack(out_pos),
             [torch.stack(m) for m in aux_masks])
+
+
+# -------------------------------------------------------------------------------------------- dynamic (eval) branch
+def unmask_attention_mask(mask: torch.Tensor, original_size):
+    """cambrian_arch.py:203-225: zero the rows / columns of a [1,h,w] grid mask that are padding of the squared image."""
+    original_w, original_h = original_size
+    cur_h, cur_w = mask.shape[1:3]
+    if original_w / original_h > cur_w / cur_h:
+        new_height = int(original_h * (cur_w / original_w))
+        padding = (cur_h - new_height) // 2
+        if padding > 0:
+            mask[:, :padding, :] = 0
+            mask[:, -padding:, :] = 0
+    else:
+        new_width = int(original_w * (cur_h / original_h))
+        padding = (cur_w - new_width) // 2
+        if padding > 0:
+            mask[:, :, :padding] = 0
+            mask[:, :, -padding:] = 0
+    return mask
+
+
+def unpad_image(tensor: torch.Tensor, original_size):
+    """cambrian_arch.py:228-256: crop a [C?,H,W,...] grid (dims 1, 2) back to the image's aspect ratio."""
+    original_width, original_height = original_size
+    current_height, current_width = tensor.shape[1:3]
+    if original_width / original_height > current_width / current_height:
+        new_height = int(original_height * (current_width / original_width))
+        padding = (current_height - new_height) // 2
+        return tensor[:, padding:current_height - padding, :]
+    new_width = int(original_width * (current_height / original_height))
+    padding = (current_width - new_width) // 2
+    return tensor[:, :, padding:current_width - padding]
+
+
+def rearrange_inference(feats: Sequence[torch.Tensor], query_side: int, image_sizes, unpad: bool = False):
+    """cambrian_arch.py:289-330."""
+    out_f, out_m = [], []
+    bs = feats[0].shape[0]
+    for f in feats:
+        side = int(f.shape[1] ** 0.5)
+        assert (side // query_side) * query_side == side
+        r = side // query_side
+        fl, ml = [], []
+        for b in range(bs):
+            m = torch.ones((1, side, side), dtype=torch.bool)
+            x = f[b].view(1, query_side, r, query_side, r, -1).permute(0, 1, 3, 2, 4, 5).contiguous()
+            if unpad:
+                x = unpad_image(x, image_sizes[b])
+            x = x.flatten(0, 2).flatten(1, 2)
+            m = unmask_attention_mask(m, image_sizes[b])
+            m = m.view(1, query_side, r, query_side, r).permute(0, 1, 3, 2, 4).contiguous()
+            if unpad:
+                m = unpad_image(m, image_sizes[b])
+            m = m.flatten(0, 2).flatten(1, 2)
+            m[m.sum(-1) == 0] = True
+            fl.append(x)
+            ml.append(m)
+        out_f.append(torch.cat(fl, 0))
+        out_m.append(torch.cat(ml, 0))
+    return out_f, out_m
+
+
+def prepare_inputs_dynamic(p: Dict[str, torch.Tensor], cfg, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+                           tower_feats: Sequence[torch.Tensor], image_sizes, embed_table: torch.Tensor,
+                           padding_side: str = "right", max_length: Optional[int] = None):
+    """The eval / generate branch (IS_XLA_AVAILABLE False) of prepare_inputs_labels_for_multimodal for the SVA
+    projector, labels = None, position_ids = None: cambrian_arch.py:366-402 (towers -> aux projectors -> connector SVA on
+    rearrange_inference lists), :422-451 (per-sample unpad + newline, in-LLM KV lists with unpad=True), :492-609 (drop
+    padding, splice the visual rows at the image token, right/left pad to the longest row).
+    Returns (inputs_embeds [B,L,H], attention_mask | None, kv_final, mask_final, final_size, ctx_final)."""
+    bs = tower_feats[0].shape[0]
+    side = int(cfg.image_token_len ** 0.5)
+    feats = [mlp_projector(p, f"mm_projector_aux_{i}.", f, True) for i, f in enumerate(tower_feats)]
+    ctx = feats[0].mean(1).view(bs, 1, 1, -1)
+    finals = []
+    for g, query_num in enumerate(cfg.query_num_list):
+        q = p["vision_query"][g].view(1, 1, 1, -1).expand(bs, query_num, -1, -1).flatten(0, 1)
+        ctx_g = ctx.expand(-1, query_num, 1, -1).flatten(0, 1)
+        qs = int(query_num ** 0.5)
+        kv, masks = rearrange_inference(feats, qs, image_sizes)
+        out = O.vision_token_sampler(p, q, ctx_g, kv, masks, prefix=f"vision_sampler_{g}.").view(bs, query_num, -1)
+        if qs != side:
+            out = out.permute(0, 2, 1).contiguous().view(bs, -1, qs, qs)
+            out = F.interpolate(out.float(), size=(side, side), mode="bilinear", align_corners=False)
+            out = out.permute(0, 2, 3, 1).contiguous().flatten(1, 2)
+        finals.append(out)
+    img = mlp_projector(p, "mm_projector.", torch.cat(finals, -1), False).view(bs, side, side, -1)
+    kv_final, mask_final = rearrange_inference(feats, side, image_sizes, unpad=True)
+    vis, final_size, ctx_final = [], [], []
+    for b in range(bs):
+        cur = unpad_image(img[b].unsqueeze(0), image_sizes[b])
+        h, w = cur.shape[1:3]
+        final_size.append((h, w))
+        cur = torch.cat((cur.view(1, h, w, -1), p["image_newline"].view(1, 1, 1, -1).expand(1, h, 1, -1)), dim=2)
+        vis.append(cur.flatten(1, 2).squeeze(0))
+        ctx_final.append(ctx[b].expand(h * w, 1, -1))
+    ctx_final = torch.cat(ctx_final, 0)
+    att = torch.ones_like(input_ids, dtype=torch.bool) if attention_mask is None else attention_mask.bool()
+    rows = []
+    for b in range(bs):
+        ids = input_ids[b][att[b]]
+        idx = torch.where(ids == IMAGE_TOKEN_INDEX)[0].tolist()
+        if not idx:
+            rows.append(embed_table[ids])
+            continue
+        assert len(idx) == 1, "one image per sample (the reference consumes image_features[cur_image_idx] per image token)"
+        rows.append(torch.cat([embed_table[ids[:idx[0]]], vis[b], embed_table[ids[idx[0] + 1:]]]))
+    if max_length is not None:
+        rows = [r[:max_length] for r in rows]
+    max_len = max(r.shape[0] for r in rows)
+    emb = torch.zeros(bs, max_len, rows[0].shape[1], dtype=rows[0].dtype)
+    new_att = torch.zeros(bs, max_len, dtype=torch.bool)
+    pos = torch.zeros(bs, max_len, dtype=torch.long)
+    for b, r in enumerate(rows):
+        n = r.shape[0]
+        if padding_side == "left":
+            emb[b, max_len - n:] = r
+            new_att[b, max_len - n:] = True
+            pos[b, max_len - n:] = torch.arange(n)
+        else:
+            emb[b, :n] = r
+            new_att[b, :n] = True
+            pos[b, :n] = torch.arange(n)
+    return emb, (None if attention_mask is None else new_att.to(attention_mask.dtype)), kv_final, mask_final, final_size, ctx_final

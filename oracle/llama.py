@@ -103,3 +103,24 @@ def lm_loss(hidden: torch.Tensor, lm_head: torch.Tensor, labels: torch.Tensor):
     shift_logits = logits[..., :-1, :].contiguous().view(-1, logits.shape[-1])
     shift_labels = labels[..., 1:].contiguous().view(-1)
     return F.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX), logits
+
+
+def sva_hook_dynamic(hidden: torch.Tensor, sampler_params: Dict[str, torch.Tensor], prefix: str, start: int, final_size,
+                     ctx: torch.Tensor, kvs: Sequence[torch.Tensor], masks: Sequence[torch.Tensor]):
+    """cambrian_llama.py:209-253 (eval branch): per sample a cur_h x (cur_w + 1) block starting at ``start`` holds the
+    latent queries + one newline column; all samples' queries are concatenated ([sum h*w, 1, H]) through the sampler
+    layer (KV lists / masks / context are already concatenated the same way) and written back."""
+    bs = len(final_size)
+    qs, nls, nums = [], [], []
+    for b in range(bs):
+        h, w = final_size[b]
+        blk = hidden[b:b + 1, start:start + h * (w + 1), :].clone().view(1, h, w + 1, -1)
+        qs.append(blk[:, :, :-1, :].contiguous().view(h * w, 1, -1))
+        nls.append(blk[:, :, -1:, :])
+        nums.append(h * w)
+    q = O.vision_token_sampler(sampler_params, torch.cat(qs, 0), ctx, [k.to(hidden.dtype) for k in kvs], masks, prefix=prefix)
+    out = hidden.clone()
+    for b, qb in enumerate(torch.split(q, nums, 0)):
+        h, w = final_size[b]
+        out[b:b + 1, start:start + h * (w + 1)] = torch.cat([qb.view(1, h, w, -1), nls[b]], 2).flatten(1, 2)
+    return out

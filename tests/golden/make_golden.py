@@ -365,6 +365,127 @@ def golden_llama():
     print("llama_small.pt written")
 
 
+def golden_arch_dynamic():
+    """The real prepare_inputs_labels_for_multimodal with IS_XLA_AVAILABLE = False: the eval / generate branch
+    (cambrian_arch.py:289-330 rearrange_inference + unpad, :422-451 per-sample unpad + newline, :492-609 variable-length
+    merge) with fake towers, non-square images and a padded batch; plus the dynamic in-LLM hook, cambrian_llama.py lines
+    209-253 exec'd verbatim."""
+    import textwrap
+    import torch.nn as nn
+    A = load_ref_arch()
+    A.IS_XLA_AVAILABLE = False
+    torch.manual_seed(4242)
+    H, vh, side, B, V = 128, 64, 4, 3, 50          # GEMM-friendly widths: the GPU test runs the HIP path on this fixture
+    tower_dims, token_lens = [64, 128], [16, 64]
+
+    class FakeTower(nn.Module):
+        def __init__(self, hidden, tokens):
+            super().__init__()
+            self.hidden_size, self.tokens, self.is_loaded = hidden, tokens, True
+            self.out = None
+
+        def load_model(self):
+            pass
+
+        def forward(self, images):
+            return self.out
+
+    towers = [FakeTower(d, t) for d, t in zip(tower_dims, token_lens)]
+
+    class Cfg:
+        pass
+
+    cfg = Cfg()
+    cfg.hidden_size, cfg.vision_hidden_size = H, vh
+    cfg.mm_vision_tower_aux_list = ["a", "b"]
+    cfg.mm_vision_tower_aux_token_len_list = token_lens
+    cfg.mm_projector_type = "sva"
+    cfg.num_query_group, cfg.query_num_list, cfg.connector_only, cfg.connector_depth = 1, [side * side], False, 2
+    cfg.image_token_len = side * side
+    cfg.num_of_vision_sampler_layers, cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers = 2, 0, 1
+    cfg._fake_towers = towers
+
+    class Base(nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+            self.embed_tokens = nn.Embedding(V, H)
+
+        @property
+        def dtype(self):
+            return torch.float32
+
+    class Model(A.CambrianMetaModel, Base):
+        pass
+
+    class LM(nn.Module, A.CambrianMetaForCausalLM):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.model = Model(cfg)
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    lm = LM()
+    with torch.no_grad():
+        lm.model.image_newline.copy_(torch.randn(H) / H ** 0.5)
+        lm.model.vision_query.mul_(1 / vh ** 0.5)
+        for n, p_ in lm.named_parameters():
+            if p_.dim() == 1 and "newline" not in n:
+                p_.add_(0.1 * torch.randn_like(p_))
+    L = 30
+    ids = torch.randint(1, V, (B, L))
+    att = torch.ones(B, L, dtype=torch.bool)
+    ids[0, 5] = -200
+    ids[1, 17] = -200
+    ids[2, 2] = -200
+    att[1, 24:] = False          # right-padded prompt
+    sizes = [(336, 336), (336, 150), (120, 400)]   # square, wide (rows unpadded), tall (columns unpadded)
+    feats = [torch.randn(B, t, d) for t, d in zip(token_lens, tower_dims)]
+    for t, f in zip(towers, feats):
+        t.out = f
+    images = [torch.zeros(B, 3, 8, 8) for _ in towers]
+    with torch.no_grad():
+        out = lm.prepare_inputs_labels_for_multimodal(ids.clone(), None, att.clone(), None, None, images, None, sizes)
+    fx = dict(cfg=dict(H=H, vh=vh, side=side, B=B, V=V, tower_dims=tower_dims, token_lens=token_lens, connector_depth=2,
+                       n_in_llm=2),
+              state={k: v.detach().clone() for k, v in lm.model.state_dict().items()},
+              ids=ids, att=att, sizes=sizes, feats=[f.clone() for f in feats],
+              out_pos=out[1], out_att=out[2], embeds=out[4].clone(), out_labels=out[5],
+              kv_final=[t.clone() for t in out[6]], mask_final=[t.clone() for t in out[7]], final_size=out[8],
+              ctx_final=out[9].clone())
+
+    # dynamic hook: lines 209-253 of cambrian_llama.py (the `else:` body of `if IS_XLA_AVAILABLE:`)
+    src = open(f"{REF}/cambrian/model/language_model/cambrian_llama.py").read().split("\n")
+    assert src[207].strip() == "else:", src[207]
+    body = textwrap.dedent("\n".join(src[208:253]))
+
+    class Self:
+        pass
+
+    me = Self()
+    me.gradient_checkpointing, me.training = False, False
+    me.vision_sampler_layers = [lm.model.vision_sampler_layers[0]]
+    S2 = max(e.shape[0] for e in [out[4][b] for b in range(B)])
+    hidden = torch.randn(B, out[4].shape[1], H)
+    p0 = 2
+    ns = dict(self=me, torch=torch, hidden_states=hidden.clone(), latent_query_start_idx=p0,
+              final_vision_feature_size=out[8], vision_tower_aux_feature_list=out[6],
+              vision_tower_aux_attention_masks_list=out[7], global_context_feature=out[9], i=0, cross_layers_start_idx=0,
+              cross_index_step=1)
+    with torch.no_grad():
+        exec(body, ns)
+    fx["hook"] = dict(p0=p0, hidden=hidden, out=ns["hidden_states"].detach().clone())
+    torch.save(fx, f"{OUT}/arch_dynamic_small.pt")
+    A.IS_XLA_AVAILABLE = True
+    print("arch_dynamic_small.pt written: embeds", tuple(out[4].shape), "final sizes", out[8])
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sva"]
     for w in which:

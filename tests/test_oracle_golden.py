@@ -191,3 +191,36 @@ def test_decoder_oracle_matches_hf_llama():
     hidden = llama.decoder_forward(p, cfg, emb, fx["pos"])
     _, logits = llama.lm_loss(hidden, p["lm_head.weight"], fx["ids"])
     assert torch.allclose(logits, fx["logits"], atol=2e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ dynamic (eval) branch
+def test_arch_oracle_dynamic_matches_reference():
+    """cambrian_arch.py eval branch (IS_XLA_AVAILABLE False) run for real by make_golden.py::golden_arch_dynamic —
+    unpad / unmask, variable-length merge with a padded row, in-LLM KV lists — vs oracle.arch.prepare_inputs_dynamic."""
+    from oracle import arch
+    fx = _load("arch_dynamic_small.pt")
+    c = fx["cfg"]
+    cfg = _NS(image_token_len=c["side"] ** 2, query_num_list=[c["side"] ** 2])
+    p = fx["state"]
+    emb, att, kv_final, mask_final, final_size, ctx_final = arch.prepare_inputs_dynamic(
+        p, cfg, fx["ids"], fx["att"], fx["feats"], fx["sizes"], p["embed_tokens.weight"])
+    assert [tuple(s) for s in final_size] == [tuple(s) for s in fx["final_size"]] == [(4, 4), (2, 4), (4, 2)]
+    assert emb.shape == fx["embeds"].shape and torch.allclose(emb, fx["embeds"], atol=2e-6, rtol=1e-5)
+    assert torch.equal(att, fx["out_att"])
+    for a, b in zip(kv_final, fx["kv_final"]):
+        assert a.shape == b.shape and torch.allclose(a, b, atol=2e-6, rtol=1e-5)
+    for a, b in zip(mask_final, fx["mask_final"]):
+        assert torch.equal(a, b)
+    assert torch.allclose(ctx_final, fx["ctx_final"], atol=2e-6, rtol=1e-5)
+    assert fx["out_pos"] is None and fx["out_labels"] is None   # position_ids / labels None in -> None out (:601-607)
+
+
+def test_hook_oracle_dynamic_matches_reference_lines():
+    """cambrian_llama.py:209-253 exec'd verbatim vs oracle.llama.sva_hook_dynamic."""
+    from oracle import llama
+    fx = _load("arch_dynamic_small.pt")
+    hk = fx["hook"]
+    out = llama.sva_hook_dynamic(hk["hidden"], fx["state"], "vision_sampler_layers.0.", hk["p0"], fx["final_size"],
+                                 fx["ctx_final"], fx["kv_final"], fx["mask_final"])
+    assert torch.allclose(out, hk["out"], atol=2e-6, rtol=1e-5)
+    assert not torch.equal(out, hk["hidden"])
