@@ -146,7 +146,7 @@ def main():
     from cambrian_amd import ops
     from cambrian_amd.train.data_layout import synthetic_batch
     from cambrian_amd.train.llm_gemm_tuning import load_tuned_llm_gemms
-    tuned = (not args.no_tuned_llm_gemms) and load_tuned_llm_gemms()
+    tuned = args.tuned_llm_gemms and load_tuned_llm_gemms()
 
     model, cfg = build_model(dev, args.llm_layers)
     params = [p for p in model.parameters() if p.requires_grad]

@@ -161,19 +161,22 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p
 
   constexpr int GPR = BN / 8;  // 8-column groups per tile row
   constexpr int GROUPS = BM * GPR;
-  for (int grp = tid; grp < GROUPS; grp += NT) {
-    const int row = grp / GPR, c8 = grp - row * GPR;
-    const int gm = m0 + row, gn = n0 + c8 * 8;
-    if (gm >= p.M || gn >= p.N) continue;
-    float v[8];
-    {
-      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8);
-      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8 + 4);
+  dispatch_act(p.slabs ? CMB_ACT_NONE : p.act, [&](auto act_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value;
+    for (int grp = tid; grp < GROUPS; grp += NT) {
+      const int row = grp / GPR, c8 = grp - row * GPR;
+      const int gm = m0 + row, gn = n0 + c8 * 8;
+      if (gm >= p.M || gn >= p.N) continue;
+      float v[8];
+      {
+        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8);
+        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8 + 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      }
+      gemm_epilogue8<T, ACT>(p, kz, gm, gn, v);
     }
-    gemm_epilogue8<T>(p, kz, gm, gn, v);
-  }
+  });
 }
 
 // out = alpha * sum_z slab[z] + beta * out   (fp32 slabs [Z][M][N]; out through the C row map)

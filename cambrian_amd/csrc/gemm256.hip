@@ -388,6 +388,7 @@ __global__ void __launch_bounds__(512) gemm_nt_256_kernel(const GemmParams p) {
   };
   typedef std::integral_constant<int, 0> I0;
   typedef std::integral_constant<int, 1> I1;
+  const int act_code = p.slabs ? CMB_ACT_NONE : p.act;
 #pragma unroll 1
   for (int qd = 0; qd < 4; ++qd) {
     const int ra = qd >> 1, cb = qd & 1;
@@ -396,21 +397,25 @@ __global__ void __launch_bounds__(512) gemm_nt_256_kernel(const GemmParams p) {
     else if (qd == 2) put(I1{}, I0{});
     else put(I1{}, I1{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the activation switch is taken once per quadrant, not once per element (the accumulators are not captured here)
+    dispatch_act(act_code, [&p, cs, lane, m0, n0, ra, cb, wr, wc, kz](auto act_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll 1
-    for (int it = 0; it < 4; ++it) {
-      const int item = it * 64 + lane;
-      const int row = item >> 2, c8 = item & 3;
-      const int gm = m0 + ra * 128 + wr * 64 + row;
-      const int gn = n0 + cb * 128 + wc * 32 + c8 * 8;
-      float v[8];
-      {
-        const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8);
-        const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8 + 4);
+      for (int it = 0; it < 4; ++it) {
+        const int item = it * 64 + lane;
+        const int row = item >> 2, c8 = item & 3;
+        const int gm = m0 + ra * 128 + wr * 64 + row;
+        const int gn = n0 + cb * 128 + wc * 32 + c8 * 8;
+        float v[8];
+        {
+          const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8);
+          const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(cs + row * CS + c8 * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+          for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+        }
+        if (gm < p.M && gn < p.N) gemm_epilogue8<bf16_t, ACT>(p, kz, gm, gn, v);
       }
-      if (gm < p.M && gn < p.N) gemm_epilogue8<bf16_t>(p, kz, gm, gn, v);
-    }
+    });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slice is rewritten by the next quadrant
   }
 }

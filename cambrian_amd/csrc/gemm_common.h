@@ -1,6 +1,7 @@
 // gemm_common.h — parameter block, MFMA wrappers and the fused row-contiguous epilogue shared by the two
 // tile configurations of the NT GEMM (gemm.hip: 128x128 / 4 waves; gemm256.hip: 256x256 / 8 waves, 8-phase).
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "gemm_layout.h"
 
@@ -46,7 +47,9 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 
 // Fused epilogue on 8 consecutive columns of output row gm (fp32 values v[8] straight from the accumulators):
 // split-K slab store, or alpha/bias/pre_out/activation/LayerScale/residual/beta and the final store.
-template <typename T>
+// ACT is a compile-time activation code: the callers dispatch on p.act ONCE, outside their row loops (a run-time
+// switch in here is re-evaluated for each of the 8 elements: ~10 scalar compare/branch instructions per element).
+template <typename T, int ACT>
 __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int gm, int gn, float (&v)[8]) {
   if (p.slabs) {  // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
     Vec8<float>::store(p.slabs + ((int64_t)kz * p.M + gm) * p.N + gn, v);
@@ -61,9 +64,9 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
     for (int e = 0; e < 8; ++e) v[e] += bb[e];
   }
   if (p.P) Vec8<T>::store(reinterpret_cast<T*>(p.P) + row_off(p.p_map, (uint32_t)gm) + gn, v);
-  if (p.act != CMB_ACT_NONE) {
+  if constexpr (ACT != CMB_ACT_NONE) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act_apply(p.act, v[e]);
+    for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
   }
   if (p.colscale) {
     float ss[8];
@@ -89,6 +92,18 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
     Vec8<float>::store(cp, v);
   } else {
     Vec8<T>::store(reinterpret_cast<T*>(p.C) + coff, v);
+  }
+}
+
+// Calls f(std::integral_constant<int, ACT>) with the compile-time twin of the run-time activation code.
+template <typename F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
+  switch (act) {
+    case CMB_ACT_GELU_ERF: f(std::integral_constant<int, CMB_ACT_GELU_ERF>{}); break;
+    case CMB_ACT_GELU_TANH: f(std::integral_constant<int, CMB_ACT_GELU_TANH>{}); break;
+    case CMB_ACT_QUICK_GELU: f(std::integral_constant<int, CMB_ACT_QUICK_GELU>{}); break;
+    case CMB_ACT_SILU: f(std::integral_constant<int, CMB_ACT_SILU>{}); break;
+    default: f(std::integral_constant<int, CMB_ACT_NONE>{}); break;
   }
 }
 
