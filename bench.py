@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
                     "config 4's partitioning) instead of all-reduce + replicated AdamW")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-tuned-llm-gemms", action="store_true", help="do not load the pre-tuned TunableOp table for the LLM's hipBLASLt GEMMs")
+    ap.add_argument("--tuned-llm-gemms", action="store_true",
+                    help="load the pre-tuned TunableOp table for the LLM's hipBLASLt GEMMs (cambrian_amd/train/llm_gemm_tuning.py); "
+                         "measured neutral in the step (the default heuristic's picks are as fast under sustained load), so off")
     ap.add_argument("--gemm-report", type=str, default=None, help="write a per-shape table of the hot-path GEMM launches (JSON)")
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (marks the line INVALID)")
     return ap.parse_args()
