@@ -1,0 +1,339 @@
+// flash_bwd.hip — backward of causal self-attention with grouped KV heads (the LLM decoder's attention:
+// S = 2048, head_dim 128, 32 query / 8 KV heads) for gfx950.  bf16 in / out, fp32 accumulation.
+//
+// Two kernels, no atomics, both on v_mfma_f32_32x32x16_bf16 with the operand arrangement of vit_attn.hip
+// (accumulator -> operand hand-off without shuffles: the MFMA's contraction slots are assigned to rows in exactly
+// the order the previous product's accumulator holds them):
+//   * flash_dq_kernel   — a workgroup owns 128 queries of one (batch, head), a LANE owns one query and walks the key
+//     tiles up to the diagonal:  S^T = K·Q^T, dP^T = V·dO^T (K, V rows from LDS, Q, dO fragments in registers),
+//     dS^T = P^T∘(dP^T − D), dQ^T += K^T·dS^T (K^T image in LDS);
+//   * flash_dkdv_kernel — a workgroup owns 128 keys of one (batch, KV head), a LANE owns one key and walks the query
+//     tiles from the diagonal on, for the 4 query heads of the group:  S = Q·K^T, dP = dO·V^T (Q, dO rows from LDS, K,
+//     V fragments in registers), dV^T += dO^T·P, dK^T += Q^T·dS (transposed Q / dO images in LDS).
+// P is recomputed from the forward's log-sum-exp (natural log of the sum of exp(scale·q·k)); D = rowsum(dO∘O) comes
+// from a small pre-pass.  7 tile products instead of the 5 of a single-pass backward, nothing is atomically
+// accumulated, results are bit-reproducible.
+// Layout: all of q, k, v, o, do, dq, dk, dv are addressed as [B, S, H, 128] through (batch, token, head) element strides
+// (token-major storage, what ops.qkv_rope produces and the attention returns); lse / D are fp32 [B, H, S].
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 128;       // head dim
+constexpr int KS = HD / 16;   // MFMA k-steps over the head dim
+constexpr int DT = HD / 32;   // 32-wide d tiles
+constexpr int LDR = HD + 8;   // row-major LDS tile row stride (elements): conflict-free ds_read_b128
+constexpr int LDT = 68;       // transposed LDS tile row stride (elements): conflict-free ds_read_b64
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct FlashParams {
+  const bf16_t *q, *k, *v, *o, *dout;
+  bf16_t *dq, *dk, *dv;
+  const float* lse;  // [B, H, S]
+  float* dvec;       // [B, H, S]  D = rowsum(dO * O)
+  int64_t q_sb, q_ss, q_sh;     // strides of q / o / do / dq (elements)
+  int64_t kv_sb, kv_ss, kv_sh;  // strides of k / v / dk / dv
+  int B, S, H, HKV;
+  float scale;
+};
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// D[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]: one wave per (token, head) row, 2 elements per lane
+__global__ void __launch_bounds__(256) flash_dvec_kernel(const FlashParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t rows = (int64_t)p.B * p.S * p.H;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const int h = (int)(r % p.H);
+    const int64_t bs = r / p.H;
+    const int s = (int)(bs % p.S);
+    const int64_t b = bs / p.S;
+    const int64_t off = b * p.q_sb + (int64_t)s * p.q_ss + (int64_t)h * p.q_sh + lane * 2;
+    const bf16x2_t a = *reinterpret_cast<const bf16x2_t*>(p.o + off);
+    const bf16x2_t g = *reinterpret_cast<const bf16x2_t*>(p.dout + off);
+    float d = (float)a[0] * (float)g[0] + (float)a[1] * (float)g[1];
+    d = wave_sum(d);
+    if (lane == 0) p.dvec[(b * p.H + h) * (int64_t)p.S + s] = d;
+  }
+}
+
+// stage a 64-row x 128 tile (rows of `src` with element stride `rs`) into a row-major LDS image (stride LDR) and,
+// if TR, also into the transposed image [128][LDT] (pairs of adjacent rows packed as one 32-bit store).
+template <bool ROWMAJOR, bool TR>
+__device__ __forceinline__ void stage_tile64(const bf16_t* src, int64_t rs, int row0, int nrows_valid, bf16_t* sR,
+                                             bf16_t* sT, int tid) {
+  // 64 rows x 16 vec8 = 1024 vec8 -> 4 per thread; thread handles row pair (2*rp, 2*rp+1), d-group dg for the
+  // transposed image so that both rows of a pair are in one thread
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    // 4 consecutive lanes cover 64 contiguous bytes of a row (global coalescing), 16 lane groups take consecutive row
+    // pairs (the transposed 32-bit stores then hit consecutive banks, 2-way at most: free for ds_write_b32)
+    const int id = tid + 256 * i;       // 0..511
+    const int dg = ((id >> 6) & 3) * 4 + (id & 3);     // d group 0..15
+    const int rp = (id >> 8) * 16 + ((id >> 2) & 15);  // row pair 0..31
+    int r0 = row0 + 2 * rp, r1 = r0 + 1;
+    r0 = r0 < nrows_valid ? r0 : nrows_valid - 1;
+    r1 = r1 < nrows_valid ? r1 : nrows_valid - 1;
+    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(src + (int64_t)r0 * rs + dg * 8);
+    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(src + (int64_t)r1 * rs + dg * 8);
+    if (ROWMAJOR) {
+      *reinterpret_cast<bf16x8_t*>(sR + (2 * rp) * LDR + dg * 8) = a;
+      *reinterpret_cast<bf16x8_t*>(sR + (2 * rp + 1) * LDR + dg * 8) = b;
+    }
+    if (TR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bf16x2_t pr;
+        pr[0] = a[e];
+        pr[1] = b[e];
+        *reinterpret_cast<bf16x2_t*>(sT + (dg * 8 + e) * LDT + 2 * rp) = pr;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dQ: grid (S/128, H, B), 256 threads.  lane = (query j = lane & 31 of the wave's 32, half g = lane >> 5).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) flash_dq_kernel(const FlashParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * LDR];
+  __shared__ __attribute__((aligned(16))) bf16_t sKT[HD * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, j = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.H / p.HKV);
+  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;  // heaviest (latest) query blocks first
+  const int q0 = qb * 128 + wave * 32;
+  const int qi = q0 + j;                                  // this lane's query (S % 128 == 0: always valid)
+  const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+  const bf16_t* dorow = p.dout + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+  bf16x8_t qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + g * 8);
+    dof[ks] = *reinterpret_cast<const bf16x8_t*>(dorow + ks * 16 + g * 8);
+  }
+  const int64_t st = ((int64_t)b * p.H + h) * p.S + qi;
+  const float lse2 = p.lse[st] * LOG2E, dq_d = p.dvec[st];
+  const float c2 = p.scale * LOG2E;
+  const bf16_t* kbase = p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
+  const bf16_t* vbase = p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
+
+  f32x16_t acc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  const int nt = (qb * 128 + 128) / 64;  // key tiles up to and including the diagonal ones
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();  // previous tile fully consumed
+    stage_tile64<true, true>(kbase, p.kv_ss, t * 64, p.S, sK, sKT, tid);
+    stage_tile64<true, false>(vbase, p.kv_ss, t * 64, p.S, sV, nullptr, tid);
+    __syncthreads();
+    if (t * 64 > q0 + 31) continue;  // whole tile above this wave's diagonal (block-uniform barriers stay matched)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + (kt * 32 + j) * LDR + ks * 16 + g * 8);
+        const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + (kt * 32 + j) * LDR + ks * 16 + g * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T[key][query]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T[key][query]
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float pr = (key <= qi) ? __builtin_amdgcn_exp2f(s[r] * c2 - lse2) : 0.f;
+        s[r] = pr * (dp[r] - dq_d);  // dS^T (the 1/sqrt(d) factor is applied once at the end)
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        bf16x8_t pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[8 * kb + e];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const bf16_t* trow = sKT + (d * 32 + j) * LDT + kt * 32 + 16 * kb + 4 * g;
+          const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(trow);
+          const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(trow + 8);
+          bf16x8_t tf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { tf[e] = lo[e]; tf[4 + e] = hi[e]; }
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf, acc[d], 0, 0, 0);  // dQ^T[d][query]
+        }
+      }
+    }
+  }
+  bf16_t* out = p.dq + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      bf16x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[d][4 * qd + e] * p.scale);
+      *reinterpret_cast<bf16x4_t*>(out + d * 32 + 8 * qd + 4 * g) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dK, dV: grid (S/128, HKV, B), 256 threads.  lane = (key j of the wave's 32, half g).  One workgroup per CU (the
+// accumulators + K/V fragments need ~350 registers).  (A software-pipelined variant — next tile's loads in registers
+// during the MFMAs, double-buffered LDS, one barrier per tile — measured SLOWER, 3.9 vs 3.4 ms: it pushes the wave to
+// 506 registers and the compiler starts shuffling values through the accumulator file.)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);   // [64][LDR]
+  bf16_t* sDO = sQ + 64 * LDR;                         // [64][LDR]
+  bf16_t* sQT = sDO + 64 * LDR;                        // [128][LDT]
+  bf16_t* sDOT = sQT + HD * LDT;                       // [128][LDT]
+  float* sLse = reinterpret_cast<float*>(sDOT + HD * LDT);  // [64] (already * log2 e)
+  float* sD = sLse + 64;                                    // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, j = lane & 31;
+  const int b = blockIdx.z, hk = blockIdx.y;
+  const int kb = blockIdx.x;  // key blocks in natural order: block 0 sees every query tile (heaviest first)
+  const int k0 = kb * 128 + wave * 32;
+  const int ki = k0 + j;
+  const int group = p.H / p.HKV;
+  const bf16_t* krow = p.k + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
+  const bf16_t* vrow = p.v + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
+  bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8_t*>(krow + ks * 16 + g * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8_t*>(vrow + ks * 16 + g * 8);
+  }
+  const float c2 = p.scale * LOG2E;
+  f32x16_t adk[DT], adv[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { adk[d][r] = 0.f; adv[d][r] = 0.f; }
+
+  const int qt0 = (kb * 128) / 64, nqt = p.S / 64;
+  for (int hq = 0; hq < group; ++hq) {
+    const int h = hk * group + hq;
+    const bf16_t* qbase = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const bf16_t* dobase = p.dout + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
+    const float* lse_b = p.lse + ((int64_t)b * p.H + h) * p.S;
+    const float* d_b = p.dvec + ((int64_t)b * p.H + h) * p.S;
+    for (int qt = qt0; qt < nqt; ++qt) {
+      __syncthreads();
+      stage_tile64<true, true>(qbase, p.q_ss, qt * 64, p.S, sQ, sQT, tid);
+      stage_tile64<true, true>(dobase, p.q_ss, qt * 64, p.S, sDO, sDOT, tid);
+      if (tid < 64) sLse[tid] = lse_b[qt * 64 + tid] * LOG2E;
+      else if (tid < 128) sD[tid - 64] = d_b[qt * 64 + tid - 64];
+      __syncthreads();
+      if (qt * 64 + 63 < k0) continue;  // every query of the tile precedes this wave's keys
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(sQ + (qs * 32 + j) * LDR + ks * 16 + g * 8);
+          const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(sDO + (qs * 32 + j) * LDR + ks * 16 + g * 8);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);    // S[query][key]
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[ks], dp, 0, 0, 0);  // dP[query][key]
+        }
+        f32x16_t pr;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int qrow = qs * 32 + 8 * r4 + 4 * g;  // rows qrow .. qrow+3 <-> registers 4*r4 .. 4*r4+3
+          const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sLse + qrow);
+          const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sD + qrow);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * r4 + e;
+            const int qidx = qt * 64 + qrow + e;
+            const float pv = (ki <= qidx) ? __builtin_amdgcn_exp2f(s[r] * c2 - l4[e]) : 0.f;
+            pr[r] = pv;
+            s[r] = pv * (dp[r] - d4[e]);  // dS
+          }
+        }
+#pragma unroll
+        for (int qb16 = 0; qb16 < 2; ++qb16) {
+          bf16x8_t pf, dsf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pf[e] = (bf16_t)pr[8 * qb16 + e];
+            dsf[e] = (bf16_t)s[8 * qb16 + e];
+          }
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const bf16_t* grow = sDOT + (d * 32 + j) * LDT + qs * 32 + 16 * qb16 + 4 * g;
+            const bf16_t* qrow_t = sQT + (d * 32 + j) * LDT + qs * 32 + 16 * qb16 + 4 * g;
+            const bf16x4_t g_lo = *reinterpret_cast<const bf16x4_t*>(grow);
+            const bf16x4_t g_hi = *reinterpret_cast<const bf16x4_t*>(grow + 8);
+            const bf16x4_t q_lo = *reinterpret_cast<const bf16x4_t*>(qrow_t);
+            const bf16x4_t q_hi = *reinterpret_cast<const bf16x4_t*>(qrow_t + 8);
+            bf16x8_t gt, qtf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gt[e] = g_lo[e]; gt[4 + e] = g_hi[e]; qtf[e] = q_lo[e]; qtf[4 + e] = q_hi[e]; }
+            adv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, adv[d], 0, 0, 0);    // dV^T[d][key]
+            adk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, adk[d], 0, 0, 0);  // dK^T[d][key]
+          }
+        }
+      }
+    }
+  }
+  bf16_t* okr = p.dk + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
+  bf16_t* ovr = p.dv + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      bf16x4_t a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = (bf16_t)(adk[d][4 * qd + e] * p.scale);
+        c[e] = (bf16_t)adv[d][4 * qd + e];
+      }
+      *reinterpret_cast<bf16x4_t*>(okr + d * 32 + 8 * qd + 4 * g) = a;
+      *reinterpret_cast<bf16x4_t*>(ovr + d * 32 + 8 * qd + 4 * g) = c;
+    }
+}
+
+}  // namespace
+
+extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                  const float* lse, int64_t B, int64_t S, int32_t H, int32_t HKV, int32_t hd,
+                                  int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
+                                  float scale, float* dvec, void* dq, void* dk, void* dv, void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !dvec || !dq || !dk || !dv) return CMB_ERR_BAD_ARG;
+  if (hd != HD || S <= 0 || (S % 128) != 0 || H <= 0 || HKV <= 0 || (H % HKV) != 0 || B < 0) return CMB_ERR_SHAPE;
+  if (B == 0) return CMB_OK;
+  if ((q_ss % 8) || (q_sh % 8) || (q_sb % 8) || (kv_ss % 8) || (kv_sh % 8) || (kv_sb % 8)) return CMB_ERR_ALIGNMENT;
+  FlashParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)o;
+  p.dout = (const bf16_t*)dout; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+  p.lse = lse; p.dvec = dvec;
+  p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
+  p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale;
+  hipStream_t s = (hipStream_t)stream;
+  {
+    int64_t rows = B * S * H, blocks = (rows + 3) / 4;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(flash_dvec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  }
+  hipLaunchKernelGGL(flash_dq_kernel, dim3((unsigned)(S / 128), (unsigned)H, (unsigned)B), dim3(256), 0, s, p);
+  constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess)
+      return CMB_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(flash_dkdv_kernel, dim3((unsigned)(S / 128), (unsigned)HKV, (unsigned)B), dim3(256), smem, s, p);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}

@@ -113,8 +113,11 @@ class LlamaAttention(nn.Module):
             q, k, v = ops.qkv_rope(F.linear(x, w_qkv), cos, sin, self.nh, self.nkv, self.hd)
             if kv_out is not None:
                 kv_out.append((k, v))
-            o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
-                                               enable_gqa=self.nkv != self.nh)
+            if attn_mask is None and torch.is_grad_enabled() and q.requires_grad and ops.causal_attention_supported(q, k):
+                o = ops.causal_attention(q, k, v)  # stock flash forward, HIP backward (flash_bwd.hip)
+            else:
+                o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
+                                                   enable_gqa=self.nkv != self.nh)
             return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
         q = ops.rope(self.q_proj(x).view(B * S, self.nh, self.hd), cos, sin).view(B, S, self.nh, self.hd).transpose(1, 2)
         k = ops.rope(self.k_proj(x).view(B * S, self.nkv, self.hd), cos, sin).view(B, S, self.nkv, self.hd).transpose(1, 2)

@@ -895,3 +895,60 @@ class SwiGLUPackedFn(torch.autograd.Function):
 
 def swiglu_packed(gu: torch.Tensor) -> torch.Tensor:
     return SwiGLUPackedFn.apply(gu)
+
+
+# ================================================================================================
+# autograd: causal self-attention of the decoder — stock forward, HIP backward
+# ================================================================================================
+def _token_major(t: torch.Tensor) -> torch.Tensor:
+    """[B,H,S,D] tensor whose storage is [B,S,H,D]-contiguous (a transposed view); copies only if it is not."""
+    tm = t.transpose(1, 2)
+    return t if tm.is_contiguous() else tm.contiguous().transpose(1, 2)
+
+
+class CausalAttnFn(torch.autograd.Function):
+    """Causal GQA attention, head_dim 128.  Forward = PyTorch's flash kernel (the same one
+    F.scaled_dot_product_attention dispatches to; it also returns the log-sum-exp); backward = cmb_flash_attn_bwd
+    (flash_bwd.hip: dQ kernel + dK/dV kernel, no atomics), which reads K/V un-expanded (grouped heads)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        L.require_gpu(q, k, v)
+        B, H, S, D = q.shape
+        HKV = k.shape[1]
+        g = H // HKV
+        ke = k if g == 1 else k.repeat_interleave(g, dim=1)
+        ve = v if g == 1 else v.repeat_interleave(g, dim=1)
+        res = torch.ops.aten._scaled_dot_product_flash_attention(q, ke, ve, 0.0, True, False)
+        out, lse = res[0], res[1]
+        ctx.save_for_backward(q, k, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, H, S, D = q.shape
+        HKV = k.shape[1]
+        q, out, dout = _token_major(q), _token_major(out), _token_major(dout)
+        k, v = _token_major(k), _token_major(v)
+        dq = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
+        dk = torch.empty((B, S, HKV, D), dtype=q.dtype, device=q.device)
+        dv = torch.empty((B, S, HKV, D), dtype=q.dtype, device=q.device)
+        dvec = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+        lse = lse.contiguous()
+        rc = L.load().cmb_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                         lse.data_ptr(), B, S, H, HKV, D, S * H * D, H * D, D, S * HKV * D, HKV * D, D,
+                                         1.0 / math.sqrt(D), dvec.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                         L.stream_ptr(q.device))
+        L.check(rc, "cmb_flash_attn_bwd")
+        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)
+
+
+def causal_attention_supported(q: torch.Tensor, k: torch.Tensor) -> bool:
+    return (q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] == 128 and q.shape[2] % 128 == 0
+            and q.shape[2] == k.shape[2] and q.shape[1] % k.shape[1] == 0)
+
+
+def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """q [B,H,S,128], k / v [B,HKV,S,128] (any strides with a contiguous last dim) -> [B,H,S,128]."""
+    return CausalAttnFn.apply(q, k, v)

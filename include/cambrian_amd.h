@@ -276,6 +276,15 @@ int cmb_cross_entropy_bwd(int dtype, const void* logits, int64_t rows, int64_t V
  * the transposes in front of the attention (HF LlamaAttention reached from cambrian_llama.py:157-166). Dh % 16 == 0. */
 int cmb_qkv_rope(int dtype, int32_t merge, void* packed, const float* cos_t, const float* sin_t, int64_t B, int64_t S,
                  int32_t nh, int32_t nkv, int32_t Dh, void* q, void* k, void* v, void* stream);
+/* Backward of causal self-attention with grouped KV heads (the decoder's F.scaled_dot_product_attention(is_causal=True,
+ * enable_gqa=True); HF LlamaAttention reached from cambrian_llama.py:157-166).  bf16, head_dim 128, S % 128 == 0.
+ * q / o / dout / dq are [B,S,H,128] and k / v / dk / dv [B,S,HKV,128] through (batch, token, head) element strides;
+ * lse fp32 [B,H,S] = log sum_j exp(scale * q.k_j) from the forward; dvec fp32 [B,H,S] is scratch (receives rowsum(dO*O)).
+ * Two MFMA kernels (dQ; dK+dV), no atomics, bit-reproducible. */
+int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                       int64_t B, int64_t S, int32_t H, int32_t HKV, int32_t hd,
+                       int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
+                       float scale, float* dvec, void* dq, void* dk, void* dv, void* stream);
 /* Backward of h = silu(g) * u (Llama MLP gate; forward is cmb_act_mul with CMB_ACT_SILU):
  * dg = dh * u * silu'(g), du = dh * silu(g); all [rows, D] with row strides. */
 int cmb_swiglu_bwd(int dtype, const void* dh, int64_t lddh, const void* g, int64_t ldg, const void* u, int64_t ldu,

@@ -1,0 +1,78 @@
+"""`-m gpu`: cmb_flash_attn_bwd (flash_bwd.hip) — gradients of causal grouped-query attention against an fp32
+restatement of softmax(QK^T/sqrt(d) + causal)V differentiated by autograd, at a small and at the LLM's shape; and the
+log-sum-exp convention of the stock forward it consumes."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, g):
+    """fp32 math on the same bf16-rounded inputs; q [B,H,S,D], k / v [B,HKV,S,D]."""
+    qf, kf, vf = q.float(), k.float().repeat_interleave(g, 1), v.float().repeat_interleave(g, 1)
+    S = q.shape[2]
+    s = qf @ kf.transpose(-1, -2) / math.sqrt(q.shape[-1])
+    s = s.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=q.device).tril_(), float("-inf"))
+    return torch.softmax(s, -1) @ vf, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,S,H,HKV", [(2, 256, 8, 2), (1, 384, 4, 4), (2, 2048, 32, 8)])
+def test_flash_bwd_matches_fp32_autograd(dev, B, S, H, HKV):
+    from cambrian_amd import ops
+    g_ = torch.Generator().manual_seed(S + H)
+    D = 128
+    # token-major storage, as ops.qkv_rope hands the tensors to the attention
+    qs = torch.randn(B, S, H, D, generator=g_).to(torch.bfloat16).to(dev)
+    ks = torch.randn(B, S, HKV, D, generator=g_).to(torch.bfloat16).to(dev)
+    vs = torch.randn(B, S, HKV, D, generator=g_).to(torch.bfloat16).to(dev)
+    w = torch.randn(B, H, S, D, generator=g_).to(dev)
+    q, k, v = (t.transpose(1, 2).detach().requires_grad_() for t in (qs, ks, vs))
+    assert ops.causal_attention_supported(q, k)
+    out = ops.causal_attention(q, k, v)
+    qr, kr, vr = (t.transpose(1, 2).detach().float().requires_grad_() for t in (qs, ks, vs))
+    ref, ref_lse = _ref(qr, kr, vr, H // HKV)
+    assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < 2e-2
+    # the stock forward's log-sum-exp is the natural log of sum exp(scale * q.k)  (what flash_bwd.hip assumes)
+    ke, ve = k.repeat_interleave(H // HKV, 1), v.repeat_interleave(H // HKV, 1)
+    lse = torch.ops.aten._scaled_dot_product_flash_attention(q, ke, ve, 0.0, True, False)[1]
+    assert lse.shape == (B, H, S) and (lse - ref_lse).abs().max().item() < 2e-2
+    (out.float() * w).sum().backward()
+    (ref * w).sum().backward()
+    for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        err = ((a.float() - b).abs().max() / b.abs().max()).item()
+        assert err < 3e-2, f"{name}: rel err {err}"
+    # bit-reproducible (no atomics)
+    q2, k2, v2 = (t.detach().clone().requires_grad_() for t in (q, k, v))
+    (ops.causal_attention(q2, k2, v2).float() * w).sum().backward()
+    assert torch.equal(q2.grad, q.grad) and torch.equal(k2.grad, k.grad) and torch.equal(v2.grad, v.grad)
+
+
+def test_flash_bwd_speed_vs_stock(dev):
+    """Not an assertion on speed (printed for the log): backward time of the HIP kernels vs PyTorch's SDPA backward."""
+    from cambrian_amd import ops
+    import torch.nn.functional as F
+    B, S, H, HKV, D = 16, 2048, 32, 8, 128
+    qs = torch.randn(B, S, H, D, device=dev).to(torch.bfloat16)
+    ks = torch.randn(B, S, HKV, D, device=dev).to(torch.bfloat16)
+    vs = torch.randn(B, S, HKV, D, device=dev).to(torch.bfloat16)
+    q, k, v = (t.transpose(1, 2).requires_grad_() for t in (qs, ks, vs))
+
+    def timed(fn):
+        o = fn()
+        gr = torch.ones_like(o)
+        for _ in range(2):
+            o.backward(gr, retain_graph=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            o.backward(gr, retain_graph=True)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5
+
+    t_hip = timed(lambda: ops.causal_attention(q, k, v))
+    t_ref = timed(lambda: F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True))
+    print(f"\nflash bwd B={B}: HIP {t_hip:.3f} ms vs stock SDPA backward {t_ref:.3f} ms")
