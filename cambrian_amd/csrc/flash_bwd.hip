@@ -1,7 +1,7 @@
-// flash_bwd.hip — backward of causal self-attention with grouped KV heads (the LLM decoder's attention:
-// S = 2048, head_dim 128, 32 query / 8 KV heads) for gfx950.  bf16 in / out, fp32 accumulation.
+// flash_bwd.hip — causal self-attention with grouped KV heads (the LLM decoder's attention: S = 2048, head_dim 128,
+// 32 query / 8 KV heads), forward and backward, for gfx950.  bf16 in / out, fp32 accumulation.
 //
-// Two kernels, no atomics, both on v_mfma_f32_32x32x16_bf16 with the operand arrangement of vit_attn.hip
+// Forward: flash_fwd_kernel (below).  Backward: two kernels, no atomics, both on v_mfma_f32_32x32x16_bf16 with the operand arrangement of vit_attn.hip
 // (accumulator -> operand hand-off without shuffles: the MFMA's contraction slots are assigned to rows in exactly
 // the order the previous product's accumulator holds them):
 //   * flash_dq_kernel   — a workgroup owns 128 queries of one (batch, head), a LANE owns one query and walks the key
@@ -90,6 +90,114 @@ __device__ __forceinline__ void stage_tile64(const bf16_t* src, int64_t rs, int 
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward: grid (S/128, H, B), 256 threads, a lane owns one query (the dQ kernel's arrangement): S^T = K·Q^T from the
+// row-major K tile, online softmax in base 2 (row max / sum need one lane^32 exchange), O^T += V^T·P^T with P going
+// accumulator -> operand without shuffles and V^T fragments from the transposed V image.  K/V heads are shared by the
+// query heads of a group without being expanded.  Writes O (bf16) and lse = log sum_j exp(scale q.k_j) (fp32).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, bf16_t* __restrict__ out,
+                                                           float* __restrict__ lse_out) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
+  __shared__ __attribute__((aligned(16))) bf16_t sVT[HD * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, j = lane & 31;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int hk = h / (p.H / p.HKV);
+  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int q0 = qb * 128 + wave * 32;
+  const int qi = q0 + j;
+  const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + g * 8);
+  const float c2 = p.scale * LOG2E;
+  const bf16_t* kbase = p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
+  const bf16_t* vbase = p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
+  f32x16_t acc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int nt = (qb * 128 + 128) / 64;
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    stage_tile64<true, false>(kbase, p.kv_ss, t * 64, p.S, sK, nullptr, tid);
+    stage_tile64<false, true>(vbase, p.kv_ss, t * 64, p.S, nullptr, sVT, tid);
+    __syncthreads();
+    if (t * 64 > q0 + 31) continue;
+    f32x16_t s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + (kt * 32 + j) * LDR + ks * 16 + g * 8);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float v = (key <= qi) ? s[kt][r] * c2 : -INFINITY;
+        s[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+    l *= alpha;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+        l += pv;
+        s[kt][r] = pv;
+      }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int kt = kb >> 1, hh = kb & 1;
+      bf16x8_t pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kt][8 * hh + e];
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const bf16_t* vrow = sVT + (d * 32 + j) * LDT + kt * 32 + 16 * hh + 4 * g;
+        const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(vrow);
+        const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(vrow + 8);
+        bf16x8_t vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[d], 0, 0, 0);  // O^T[d][query]
+      }
+    }
+  }
+  const float l_tot = l + __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l_tot;
+  bf16_t* orow = out + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      bf16x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[d][4 * qd + e] * inv);
+      *reinterpret_cast<bf16x4_t*>(orow + d * 32 + 8 * qd + 4 * g) = o;
+    }
+  if (g == 0) lse_out[((int64_t)b * p.H + h) * p.S + qi] = (m + __builtin_amdgcn_logf(l_tot)) * (1.0f / LOG2E);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -334,6 +442,24 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
     attr_done = true;
   }
   hipLaunchKernelGGL(flash_dkdv_kernel, dim3((unsigned)(S / 128), (unsigned)HKV, (unsigned)B), dim3(256), smem, s, p);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t B, int64_t S, int32_t H, int32_t HKV,
+                                  int32_t hd, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss,
+                                  int64_t kv_sh, float scale, void* out, float* lse, void* stream) {
+  if (!q || !k || !v || !out || !lse) return CMB_ERR_BAD_ARG;
+  if (hd != HD || S <= 0 || (S % 128) != 0 || H <= 0 || HKV <= 0 || (H % HKV) != 0 || B < 0) return CMB_ERR_SHAPE;
+  if (B == 0) return CMB_OK;
+  if ((q_ss % 8) || (q_sh % 8) || (q_sb % 8) || (kv_ss % 8) || (kv_sh % 8) || (kv_sb % 8)) return CMB_ERR_ALIGNMENT;
+  FlashParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = nullptr; p.dout = nullptr;
+  p.dq = p.dk = p.dv = nullptr; p.lse = nullptr; p.dvec = nullptr;
+  p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
+  p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale;
+  hipLaunchKernelGGL(flash_fwd_kernel, dim3((unsigned)(S / 128), (unsigned)H, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, p, (bf16_t*)out, lse);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

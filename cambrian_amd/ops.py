@@ -907,20 +907,23 @@ def _token_major(t: torch.Tensor) -> torch.Tensor:
 
 
 class CausalAttnFn(torch.autograd.Function):
-    """Causal GQA attention, head_dim 128.  Forward = PyTorch's flash kernel (the same one
-    F.scaled_dot_product_attention dispatches to; it also returns the log-sum-exp); backward = cmb_flash_attn_bwd
-    (flash_bwd.hip: dQ kernel + dK/dV kernel, no atomics), which reads K/V un-expanded (grouped heads)."""
+    """Causal GQA attention, head_dim 128, on flash_bwd.hip: forward kernel (online softmax, writes the log-sum-exp),
+    backward = dQ kernel + dK/dV kernel (no atomics).  K/V are read un-expanded (grouped heads): no
+    repeat_interleave copies of K and V per layer as F.scaled_dot_product_attention(enable_gqa=True) makes."""
 
     @staticmethod
     def forward(ctx, q, k, v):
         L.require_gpu(q, k, v)
         B, H, S, D = q.shape
         HKV = k.shape[1]
-        g = H // HKV
-        ke = k if g == 1 else k.repeat_interleave(g, dim=1)
-        ve = v if g == 1 else v.repeat_interleave(g, dim=1)
-        res = torch.ops.aten._scaled_dot_product_flash_attention(q, ke, ve, 0.0, True, False)
-        out, lse = res[0], res[1]
+        q, k, v = _token_major(q), _token_major(k), _token_major(v)
+        out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+        rc = L.load().cmb_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, S, H, HKV, D, S * H * D, H * D, D,
+                                         S * HKV * D, HKV * D, D, 1.0 / math.sqrt(D), out.data_ptr(), lse.data_ptr(),
+                                         L.stream_ptr(q.device))
+        L.check(rc, "cmb_flash_attn_fwd")
+        out = out.transpose(1, 2)  # [B,H,S,D] view of token-major storage: the o_proj input needs no copy
         ctx.save_for_backward(q, k, v, out, lse)
         return out
 

@@ -281,6 +281,10 @@ int cmb_qkv_rope(int dtype, int32_t merge, void* packed, const float* cos_t, con
  * q / o / dout / dq are [B,S,H,128] and k / v / dk / dv [B,S,HKV,128] through (batch, token, head) element strides;
  * lse fp32 [B,H,S] = log sum_j exp(scale * q.k_j) from the forward; dvec fp32 [B,H,S] is scratch (receives rowsum(dO*O)).
  * Two MFMA kernels (dQ; dK+dV), no atomics, bit-reproducible. */
+/* Forward of the same attention: out [B,S,H,128] (strides of q), lse fp32 [B,H,S]. */
+int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t B, int64_t S, int32_t H, int32_t HKV,
+                       int32_t hd, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
+                       float scale, void* out, float* lse, void* stream);
 int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                        int64_t B, int64_t S, int32_t H, int32_t HKV, int32_t hd,
                        int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,

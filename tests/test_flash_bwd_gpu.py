@@ -34,10 +34,13 @@ def test_flash_bwd_matches_fp32_autograd(dev, B, S, H, HKV):
     qr, kr, vr = (t.transpose(1, 2).detach().float().requires_grad_() for t in (qs, ks, vs))
     ref, ref_lse = _ref(qr, kr, vr, H // HKV)
     assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < 2e-2
-    # the stock forward's log-sum-exp is the natural log of sum exp(scale * q.k)  (what flash_bwd.hip assumes)
-    ke, ve = k.repeat_interleave(H // HKV, 1), v.repeat_interleave(H // HKV, 1)
-    lse = torch.ops.aten._scaled_dot_product_flash_attention(q, ke, ve, 0.0, True, False)[1]
+    # forward log-sum-exp: natural log of sum exp(scale * q.k), and interchangeable with the stock flash kernel's
+    lse = out.grad_fn.saved_tensors[4]
     assert lse.shape == (B, H, S) and (lse - ref_lse).abs().max().item() < 2e-2
+    ke, ve = k.repeat_interleave(H // HKV, 1), v.repeat_interleave(H // HKV, 1)
+    res = torch.ops.aten._scaled_dot_product_flash_attention(q, ke, ve, 0.0, True, False)
+    assert (res[1] - lse).abs().max().item() < 2e-2
+    assert ((res[0].float() - out.float()).abs().max() / ref.abs().max()).item() < 2e-2
     (out.float() * w).sum().backward()
     (ref * w).sum().backward()
     for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
@@ -76,3 +79,20 @@ def test_flash_bwd_speed_vs_stock(dev):
     t_hip = timed(lambda: ops.causal_attention(q, k, v))
     t_ref = timed(lambda: F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True))
     print(f"\nflash bwd B={B}: HIP {t_hip:.3f} ms vs stock SDPA backward {t_ref:.3f} ms")
+
+    def timed_fwd(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5
+
+    with torch.no_grad():
+        f_hip = timed_fwd(lambda: ops.causal_attention(q, k, v))
+        f_ref = timed_fwd(lambda: F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True))
+    print(f"flash fwd B={B}: HIP {f_hip:.3f} ms vs stock SDPA forward (incl. K/V head expansion) {f_ref:.3f} ms")
