@@ -372,6 +372,106 @@ __global__ void __launch_bounds__(256) rope_apply_kernel(T* __restrict__ x, cons
   }
 }
 
+// y = rmsnorm(x + res) * w, sum = x + res (the residual stream) in ONE pass: the decoder's "h = h + attn(...);
+// mlp_in = post_attention_layernorm(h)" (HF LlamaDecoderLayer reached from cambrian_llama.py:157-166).
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) add_rmsnorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                              int64_t rows, int D, const float* __restrict__ w, float eps,
+                                                              T* __restrict__ sum, T* __restrict__ y,
+                                                              float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nvec = D >> 3;
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    float v[NCH][8];
+    const T* xr = x + row * (int64_t)D;
+    const T* rr = res + row * (int64_t)D;
+    T* sr = sum + row * (int64_t)D;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float a[8];
+        Vec8<T>::load(xr + vi * 8, v[c]);
+        Vec8<T>::load(rr + vi * 8, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = (float)(T)(v[c][e] + a[e]);  // the stream is stored in T: normalise what is stored
+        Vec8<T>::store(sr + vi * 8, v[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[c][e] * v[c][e];
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(s) / (float)D + eps);
+    T* yr = y + row * (int64_t)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float ww[8], o[8];
+        load8f(w + vi * 8, ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = ww[e] * (v[c][e] * rstd);
+        Vec8<T>::store(yr + vi * 8, o);
+      }
+    }
+    if (lane == 0) rstd_out[row] = rstd;
+  }
+}
+
+// dx = rmsnorm_backward(dy; x, w, rstd) + dadd, single pass: x and dy of the row stay in registers in their storage
+// type between the reduction and the update (frozen weight: no dw).
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) rmsnorm_bwd_add_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const T* __restrict__ dadd, int64_t rows, int D,
+                                                              const float* __restrict__ w, const float* __restrict__ rstd_in,
+                                                              T* __restrict__ dx) {
+  typedef T vec_t __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nvec = D >> 3;
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    const float rstd = rstd_in[row];
+    const T* xr = x + row * (int64_t)D;
+    const T* dyr = dy + row * (int64_t)D;
+    vec_t xs[NCH], ds[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        xs[c] = *reinterpret_cast<const vec_t*>(xr + vi * 8);
+        ds[c] = *reinterpret_cast<const vec_t*>(dyr + vi * 8);
+        float ww[8];
+        load8f(w + vi * 8, ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)ds[c][e] * ww[e] * ((float)xs[c][e] * rstd);
+      }
+    }
+    const float c2 = wave_sum(s) / (float)D;
+    T* dxr = dx + row * (int64_t)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float ww[8], o[8];
+        load8f(w + vi * 8, ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = ((float)ds[c][e] * ww[e] - (float)xs[c][e] * rstd * c2) * rstd;
+        if (dadd) {
+          float a[8];
+          Vec8<T>::load(dadd + row * (int64_t)D + vi * 8, a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += a[e];
+        }
+        Vec8<T>::store(dxr + vi * 8, o);
+      }
+    }
+  }
+}
+
 int nch_for(int64_t D) {
   const int64_t need = (D / 8 + 63) / 64;
   if (need <= 2) return 2;
@@ -559,6 +659,50 @@ extern "C" int cmb_rope_apply(int dtype, void* x, const float* cos_t, const floa
                        sin_t, ntok, (int)H, (int)Dh, row_stride, inverse);
   else
     return CMB_ERR_BAD_ARG;
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_add_rmsnorm_fwd(int dtype, const void* x, const void* res, int64_t rows, int64_t D, const float* w,
+                                   float eps, void* sum, void* y, float* rstd, void* stream) {
+  if (!x || !res || !w || !sum || !y || !rstd || rows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  const int nch = nch_for(D);
+  if (nch < 0) return CMB_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CMB_BF16) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<bf16_t, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,
+                                         (const bf16_t*)x, (const bf16_t*)res, rows, (int)D, w, eps, (bf16_t*)sum,
+                                         (bf16_t*)y, rstd));
+  } else if (dtype == CMB_F32) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((add_rmsnorm_fwd_kernel<float, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,
+                                         (const float*)x, (const float*)res, rows, (int)D, w, eps, (float*)sum,
+                                         (float*)y, rstd));
+  } else {
+    return CMB_ERR_BAD_ARG;
+  }
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_rmsnorm_bwd_add(int dtype, const void* dy, const void* x, const void* dadd, int64_t rows, int64_t D,
+                                   const float* w, const float* rstd, void* dx, void* stream) {
+  if (!dy || !x || !w || !rstd || !dx || rows < 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  const int nch = nch_for(D);
+  if (nch < 0) return CMB_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CMB_BF16) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((rmsnorm_bwd_add_kernel<bf16_t, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,
+                                         (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)dadd, rows, (int)D, w, rstd,
+                                         (bf16_t*)dx));
+  } else if (dtype == CMB_F32) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((rmsnorm_bwd_add_kernel<float, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,
+                                         (const float*)dy, (const float*)x, (const float*)dadd, rows, (int)D, w, rstd,
+                                         (float*)dx));
+  } else {
+    return CMB_ERR_BAD_ARG;
+  }
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

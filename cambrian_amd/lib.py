@@ -83,6 +83,8 @@ SIGNATURES = {
                                     _i32, _p, _p, _p, _p]),
     "cmb_rmsnorm_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _p, _f, _p, _p, _p]),
     "cmb_rmsnorm_bwd": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
+    "cmb_add_rmsnorm_fwd": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _p, _f, _p, _p, _p, _p]),
+    "cmb_rmsnorm_bwd_add": (C.c_int, [C.c_int, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "cmb_rope_table": (C.c_int, [_p, _i64, _i64, _f, _p, _p, _p]),
     "cmb_rope_apply": (C.c_int, [C.c_int, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p]),
     "cmb_sva_attn_fwd": (C.c_int, [C.POINTER(SvaDesc), _p]),

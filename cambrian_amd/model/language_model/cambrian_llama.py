@@ -151,8 +151,10 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = HipRMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device, dtype)
 
     def forward(self, x, cos, sin, attn_mask, kv_out: Optional[list] = None):
-        x = x + self.self_attn(self.input_layernorm(x), cos, sin, attn_mask, kv_out)
-        return x + self.mlp(self.post_attention_layernorm(x))
+        a = self.self_attn(self.input_layernorm(x), cos, sin, attn_mask, kv_out)
+        n2 = self.post_attention_layernorm
+        x, h = ops.add_rmsnorm(x, a, n2.weight, n2.variance_epsilon)  # x + a and norm(x + a) in one pass
+        return x + self.mlp(h)
 
     def decode(self, x, cos, sin, kcache, vcache, t, key_mask):
         x = x + self.self_attn.decode(self.input_layernorm(x), cos, sin, kcache, vcache, t, key_mask)

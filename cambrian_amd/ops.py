@@ -606,9 +606,14 @@ class RmsNormFn(torch.autograd.Function):
         dy2 = _as_dtype_contig(dy.reshape(rows, D), x2.dtype)
         dx = torch.empty_like(x2)
         dw = torch.zeros((D,), dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[1] else None
-        rc = L.load().cmb_rmsnorm_bwd(L.dtype_code(x2.dtype), dy2.data_ptr(), x2.data_ptr(), rows, D, w32.data_ptr(),
-                                      rstd.data_ptr(), dx.data_ptr(), L.ptr(dw), L.stream_ptr(x2.device))
-        L.check(rc, "cmb_rmsnorm_bwd")
+        if dw is None:  # frozen weight: single-pass kernel (row kept in registers)
+            rc = L.load().cmb_rmsnorm_bwd_add(L.dtype_code(x2.dtype), dy2.data_ptr(), x2.data_ptr(), None, rows, D,
+                                              w32.data_ptr(), rstd.data_ptr(), dx.data_ptr(), L.stream_ptr(x2.device))
+            L.check(rc, "cmb_rmsnorm_bwd_add")
+        else:
+            rc = L.load().cmb_rmsnorm_bwd(L.dtype_code(x2.dtype), dy2.data_ptr(), x2.data_ptr(), rows, D, w32.data_ptr(),
+                                          rstd.data_ptr(), dx.data_ptr(), L.ptr(dw), L.stream_ptr(x2.device))
+            L.check(rc, "cmb_rmsnorm_bwd")
         if dw is not None and ctx.w_dtype != torch.float32:
             dw = dw.to(ctx.w_dtype)
         return dx.view(ctx.shape), dw, None
@@ -955,3 +960,61 @@ def causal_attention_supported(q: torch.Tensor, k: torch.Tensor) -> bool:
 def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """q [B,H,S,128], k / v [B,HKV,S,128] (any strides with a contiguous last dim) -> [B,H,S,128]."""
     return CausalAttnFn.apply(q, k, v)
+
+
+class AddRmsNormFn(torch.autograd.Function):
+    """(s, y) = (x + delta, rmsnorm(x + delta) * w) in one pass — the decoder layer's "h = h + attn; mlp_in = norm(h)".
+    Backward: d(x) = d(delta) = g_s + rmsnorm_backward(g_y), also one pass when the weight is frozen."""
+
+    @staticmethod
+    def forward(ctx, x, delta, weight, eps: float):
+        L.require_gpu(x, delta, weight)
+        shape = x.shape
+        D = shape[-1]
+        x2, d2 = x.reshape(-1, D), delta.reshape(-1, D)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        d2 = d2 if d2.is_contiguous() else d2.contiguous()
+        if d2.dtype != x2.dtype:
+            d2 = d2.to(x2.dtype)
+        w32 = k_cast(weight, torch.float32)
+        rows = x2.shape[0]
+        s = torch.empty_like(x2)
+        y = torch.empty_like(x2)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        rc = L.load().cmb_add_rmsnorm_fwd(L.dtype_code(x2.dtype), x2.data_ptr(), d2.data_ptr(), rows, D, w32.data_ptr(), eps,
+                                          s.data_ptr(), y.data_ptr(), rstd.data_ptr(), L.stream_ptr(x.device))
+        L.check(rc, "cmb_add_rmsnorm_fwd")
+        ctx.save_for_backward(s, w32, rstd)
+        ctx.shape, ctx.w_dtype = shape, weight.dtype
+        return s.view(shape), y.view(shape)
+
+    @staticmethod
+    def backward(ctx, g_s, g_y):
+        s, w32, rstd = ctx.saved_tensors
+        rows, D = s.shape
+        need_w = ctx.needs_input_grad[2]
+        if g_y is None:
+            return g_s, g_s, None, None
+        gy = _as_dtype_contig(g_y.reshape(rows, D), s.dtype)
+        gs = None if g_s is None else _as_dtype_contig(g_s.reshape(rows, D), s.dtype)
+        dw = None
+        dx = torch.empty_like(s)
+        if need_w:  # trainable norm weight (finetune stage): the two-pass kernel that also reduces dw
+            dw = torch.zeros((D,), dtype=torch.float32, device=s.device)
+            rc = L.load().cmb_rmsnorm_bwd(L.dtype_code(s.dtype), gy.data_ptr(), s.data_ptr(), rows, D, w32.data_ptr(),
+                                          rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), L.stream_ptr(s.device))
+            L.check(rc, "cmb_rmsnorm_bwd")
+            if gs is not None:
+                dx = dx + gs
+            if ctx.w_dtype != torch.float32:
+                dw = dw.to(ctx.w_dtype)
+        else:
+            rc = L.load().cmb_rmsnorm_bwd_add(L.dtype_code(s.dtype), gy.data_ptr(), s.data_ptr(), L.ptr(gs), rows, D,
+                                              w32.data_ptr(), rstd.data_ptr(), dx.data_ptr(), L.stream_ptr(s.device))
+            L.check(rc, "cmb_rmsnorm_bwd_add")
+        dx = dx.view(ctx.shape)
+        return dx, dx, dw, None
+
+
+def add_rmsnorm(x, delta, weight, eps: float = 1e-6):
+    return AddRmsNormFn.apply(x, delta, weight, eps)

@@ -141,6 +141,15 @@ int cmb_rmsnorm_fwd(int dtype, const void* x, int64_t rows, int64_t D, const flo
 int cmb_rmsnorm_bwd(int dtype, const void* dy, const void* x, int64_t rows, int64_t D,
                     const float* w, const float* rstd, void* dx, float* dw, void* stream);
 
+/* Fused residual add + RMSNorm of the decoder layer ("h = h + attn(...); x = post_attention_layernorm(h)"):
+ * sum = x + res (stored in the compute dtype), y = rmsnorm(sum) * w, one pass; rstd fp32 [rows] for the backward. */
+int cmb_add_rmsnorm_fwd(int dtype, const void* x, const void* res, int64_t rows, int64_t D, const float* w, float eps,
+                        void* sum, void* y, float* rstd, void* stream);
+/* dx = rmsnorm_backward(dy; x, w, rstd) + dadd (dadd may be NULL), single pass, frozen weight (no dw): the gradient of
+ * the residual stream and of the normalised branch leave as one tensor. */
+int cmb_rmsnorm_bwd_add(int dtype, const void* dy, const void* x, const void* dadd, int64_t rows, int64_t D,
+                        const float* w, const float* rstd, void* dx, void* stream);
+
 /* RoPE (rotate-half form): x[t,h,:] = x*cos + rotate_half(x)*sin with
  * cos/sin = cos/sin(position_ids[t] * base^(-2i/Dh)) evaluated in fp32
  * (phi3/modeling_phi3.py:114-141,257-281 and the HF Llama equivalent).

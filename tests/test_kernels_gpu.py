@@ -502,3 +502,32 @@ def test_swiglu_packed(dev, name, dt):
     out = ops.swiglu_packed(x)
     (out.float() * w.to(dev)).sum().backward()
     assert rel_err(out, ref) < TOL[name] and rel_err(x.grad, r.grad) < TOL[name]
+
+
+@pytest.mark.parametrize("name,dt", DTYPES)
+@pytest.mark.parametrize("frozen", [True, False])
+def test_add_rmsnorm_fused(dev, name, dt, frozen):
+    """(x + d, rmsnorm(x + d) * w) and its backward vs the unfused torch graph (the sum is rounded to the storage type
+    before it is normalised, exactly as the separate add + norm do)."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(41)
+    rows, D = 37, 4096
+    x, d = _rand(g, 3, rows, D).to(dt), _rand(g, 3, rows, D).to(dt)
+    w = (1 + 0.1 * _rand(g, D))
+    ws, wy = _rand(g, 3, rows, D), _rand(g, 3, rows, D)
+    xr, dr = x.float().clone().requires_grad_(), d.float().clone().requires_grad_()
+    wr = w.clone().requires_grad_(not frozen)
+    sr = (xr + dr).to(dt).float() if dt != torch.float32 else xr + dr
+    sr_g = xr + dr  # gradient path of the sum (the rounding has zero derivative almost everywhere: straight-through)
+    sr = sr_g + (sr - sr_g).detach()
+    yr = wr * (sr * torch.rsqrt(sr.pow(2).mean(-1, keepdim=True) + 1e-5))
+    ((sr * ws).sum() + (yr * wy).sum()).backward()
+    xd, dd = x.detach().to(dev).requires_grad_(), d.detach().to(dev).requires_grad_()
+    wd = w.to(dev).requires_grad_(not frozen)
+    s, y = ops.add_rmsnorm(xd, dd, wd, 1e-5)
+    ((s.float() * ws.to(dev)).sum() + (y.float() * wy.to(dev)).sum()).backward()
+    tol = TOL[name]
+    assert rel_err(s, sr) < tol and rel_err(y, yr) < tol
+    assert rel_err(xd.grad, xr.grad) < tol and torch.equal(xd.grad, dd.grad)
+    if not frozen:
+        assert rel_err(wd.grad, wr.grad) < (tol if name == "fp32" else 3e-2)
