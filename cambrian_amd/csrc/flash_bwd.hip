@@ -291,9 +291,9 @@ __global__ void __launch_bounds__(256, 2) flash_dq_kernel(const FlashParams p) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // dK, dV: grid (S/128, HKV, B), 256 threads.  lane = (key j of the wave's 32, half g).  One workgroup per CU (the
-// accumulators + K/V fragments need ~350 registers).  (A software-pipelined variant — next tile's loads in registers
-// during the MFMAs, double-buffered LDS, one barrier per tile — measured SLOWER, 3.9 vs 3.4 ms: it pushes the wave to
-// 506 registers and the compiler starts shuffling values through the accumulator file.)
+// accumulators + K/V fragments need ~350 registers), so the HBM/L2 latency of the next query tile is hidden inside the
+// workgroup by a register prefetch (see the loop).  (A double-buffered-LDS variant with one barrier per tile measured
+// slower: 506 registers, values shuffled through the accumulator file.)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -326,19 +326,60 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
     for (int r = 0; r < 16; ++r) { adk[d][r] = 0.f; adv[d][r] = 0.f; }
 
   const int qt0 = (kb * 128) / 64, nqt = p.S / 64;
+  // Register prefetch: the global loads of the NEXT (head, query tile) are issued right after the barrier that
+  // publishes the current tile and stay in flight during its 64 MFMAs; they are written to LDS after the next barrier.
+  // Thread <-> (row pair rp, d group dg) x 2 passes, as in stage_tile64.
+  const int sid1 = tid + 256;
+  const int dg0 = ((tid >> 6) & 3) * 4 + (tid & 3), rp0 = (tid >> 8) * 16 + ((tid >> 2) & 15);
+  const int dg1 = ((sid1 >> 6) & 3) * 4 + (sid1 & 3), rp1 = (sid1 >> 8) * 16 + ((sid1 >> 2) & 15);
+  const int64_t o00 = (int64_t)(2 * rp0) * p.q_ss + dg0 * 8, o01 = o00 + p.q_ss;
+  const int64_t o10 = (int64_t)(2 * rp1) * p.q_ss + dg1 * 8, o11 = o10 + p.q_ss;
+  bf16x8_t rq00, rq01, rq10, rq11, rg00, rg01, rg10, rg11;
+  float rl = 0.f;
+#define DKDV_LOAD(h_, qt_)                                                                                    \
+  do {                                                                                                        \
+    const bf16_t* qb_ = p.q + (int64_t)b * p.q_sb + (int64_t)(h_) * p.q_sh + (int64_t)((qt_) * 64) * p.q_ss;   \
+    const bf16_t* gb_ = p.dout + (int64_t)b * p.q_sb + (int64_t)(h_) * p.q_sh + (int64_t)((qt_) * 64) * p.q_ss; \
+    rq00 = *reinterpret_cast<const bf16x8_t*>(qb_ + o00);                                                     \
+    rq01 = *reinterpret_cast<const bf16x8_t*>(qb_ + o01);                                                     \
+    rq10 = *reinterpret_cast<const bf16x8_t*>(qb_ + o10);                                                     \
+    rq11 = *reinterpret_cast<const bf16x8_t*>(qb_ + o11);                                                     \
+    rg00 = *reinterpret_cast<const bf16x8_t*>(gb_ + o00);                                                     \
+    rg01 = *reinterpret_cast<const bf16x8_t*>(gb_ + o01);                                                     \
+    rg10 = *reinterpret_cast<const bf16x8_t*>(gb_ + o10);                                                     \
+    rg11 = *reinterpret_cast<const bf16x8_t*>(gb_ + o11);                                                     \
+    const int64_t st_ = ((int64_t)b * p.H + (h_)) * p.S + (qt_) * 64;                                         \
+    /* raw values only: any arithmetic on a loaded value here would force s_waitcnt vmcnt(0) before the MFMAs */ \
+    if (tid < 64) rl = p.lse[st_ + tid];                                                                      \
+    else if (tid < 128) rl = p.dvec[st_ + tid - 64];                                                          \
+  } while (0)
+#define DKDV_PUT(sR_, sT_, a_, b_, rp_, dg_)                                          \
+  do {                                                                                \
+    *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_)) * LDR + (dg_) * 8) = (a_);       \
+    *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_) + 1) * LDR + (dg_) * 8) = (b_);   \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                \
+      bf16x2_t pr_;                                                                   \
+      pr_[0] = (a_)[e_];                                                              \
+      pr_[1] = (b_)[e_];                                                              \
+      *reinterpret_cast<bf16x2_t*>((sT_) + ((dg_) * 8 + e_) * LDT + 2 * (rp_)) = pr_; \
+    }                                                                                 \
+  } while (0)
+  DKDV_LOAD(hk * group, qt0);
   for (int hq = 0; hq < group; ++hq) {
     const int h = hk * group + hq;
-    const bf16_t* qbase = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
-    const bf16_t* dobase = p.dout + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
-    const float* lse_b = p.lse + ((int64_t)b * p.H + h) * p.S;
-    const float* d_b = p.dvec + ((int64_t)b * p.H + h) * p.S;
     for (int qt = qt0; qt < nqt; ++qt) {
+      __syncthreads();  // the previous tile is fully consumed
+      DKDV_PUT(sQ, sQT, rq00, rq01, rp0, dg0);
+      DKDV_PUT(sQ, sQT, rq10, rq11, rp1, dg1);
+      DKDV_PUT(sDO, sDOT, rg00, rg01, rp0, dg0);
+      DKDV_PUT(sDO, sDOT, rg10, rg11, rp1, dg1);
+      if (tid < 128) sLse[tid] = tid < 64 ? rl * LOG2E : rl;  // [0,64) lse * log2 e, [64,128) D  (sD == sLse + 64)
       __syncthreads();
-      stage_tile64<true, true>(qbase, p.q_ss, qt * 64, p.S, sQ, sQT, tid);
-      stage_tile64<true, true>(dobase, p.q_ss, qt * 64, p.S, sDO, sDOT, tid);
-      if (tid < 64) sLse[tid] = lse_b[qt * 64 + tid] * LOG2E;
-      else if (tid < 128) sD[tid - 64] = d_b[qt * 64 + tid - 64];
-      __syncthreads();
+      {
+        const bool last_q = (qt + 1 == nqt);
+        const int nh = last_q ? h + 1 : h, nq = last_q ? qt0 : qt + 1;
+        if (!(last_q && hq + 1 == group)) DKDV_LOAD(nh, nq);
+      }
       if (qt * 64 + 63 < k0) continue;  // every query of the tile precedes this wave's keys
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs) {
@@ -393,6 +434,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
       }
     }
   }
+#undef DKDV_LOAD
+#undef DKDV_PUT
   bf16_t* okr = p.dk + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
   bf16_t* ovr = p.dv + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
 #pragma unroll
