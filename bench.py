@@ -118,6 +118,19 @@ def cpu_baseline():
                       f"{step_gflop:.0f} GFLOP/img (towers fwd + 3x SVA side)"}
 
 
+def pmc_note():
+    path = os.path.join(ROOT, "profiles", "pmc_gemm256.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return {"shape_MNK": d["shape"], "algorithmic_bytes": d["algorithmic_bytes_per_launch"],
+                "what": "rocprofv3 --pmc passes on the launch shape with the largest share of the kernel's time "
+                        "(profiles/pmc_gemm256.json): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; FETCH counts L2->fabric "
+                        "reads incl. Infinity-Cache hits"}
+    except Exception:
+        return None
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
     MI355X_MICROARCH.md §HBM), collected by tools/pmc_traffic.sh over this same command and committed under profiles/;
@@ -229,7 +242,7 @@ def main():
             ach = f256 / (ms256 * 1e-3) / 1e12 if ms256 > 0 else 0.0
             line["roofline"] = {"bound": "mfma", "kernel": "cmb_gemm_detail::gemm_nt_256_kernel (bf16, 256x256x64, 8 waves)",
                                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(), "traffic_of": pmc_note(),
                                 "launches": n256, "avg_launch_us": ms256 * 1e3 / max(n256, 1),
                                 "flop_per_launch_avg": f256 / max(n256, 1),
                                 "share_of_step": ms256 / (elapsed * 1e3),
