@@ -50,6 +50,44 @@ class SimpleImageTransform:
         return (x - mean) / std
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Real-weight loading.  The reference downloads the towers (HF ``from_pretrained``:
+# clip_encoder.py:47, dino_encoder.py:81; open_clip hub: siglip_encoder.py:53-56, clip_convnext_encoder.py:84-90).
+# Here a tower looks for a LOCAL checkpoint — the name itself if it is a directory, else
+# ``$CAMBRIAN_WEIGHTS_DIR/<name>``, ``…/<name with '/' -> '--'>`` or the HF cache layout ``models--<org>--<repo>`` — and
+# maps its keys onto the canonical names of the native trunks (weight_maps.py); without one it falls back to seeded
+# random-init weights of the same architecture and says so.
+# ------------------------------------------------------------------------------------------------------------------
+_CKPT_FILES = ("model.safetensors", "open_clip_model.safetensors", "pytorch_model.bin", "open_clip_pytorch_model.bin")
+
+
+def find_local_checkpoint(name: str):
+    import glob
+    import os
+    roots = []
+    if os.path.isdir(name):
+        roots.append(name)
+    wd = os.environ.get("CAMBRIAN_WEIGHTS_DIR")
+    if wd:
+        flat = name.replace("hf-hub:", "")
+        roots += [os.path.join(wd, flat), os.path.join(wd, flat.replace("/", "--"))]
+        roots += glob.glob(os.path.join(wd, "models--" + flat.replace("/", "--"), "snapshots", "*"))
+    for r in roots:
+        for fn in _CKPT_FILES:
+            path = os.path.join(r, fn)
+            if os.path.isfile(path):
+                return path
+    return None
+
+
+def load_checkpoint_state(path: str):
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+
+
 class BaseVisionTower(nn.Module):
     """base_encoder.py:33-134."""
 

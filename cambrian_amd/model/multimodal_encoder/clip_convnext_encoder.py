@@ -5,7 +5,8 @@ from types import SimpleNamespace
 
 import torch
 
-from .base_encoder import BaseVisionTower, ProcessorWrapper, SimpleImageTransform, logger
+from .base_encoder import (BaseVisionTower, ProcessorWrapper, SimpleImageTransform, find_local_checkpoint,
+                           load_checkpoint_state, logger)
 from .convnext import ConvNeXtConfig, ConvNeXtTrunk
 
 CONVNEXT_ARCH = {
@@ -62,9 +63,19 @@ class CLIPConvNextTower(BaseVisionTower):
         cfg = ConvNeXtConfig(**self._arch)
         dtype = getattr(self, "_compute_dtype", torch.bfloat16)
         gen = torch.Generator(device=self._target_device()).manual_seed(self._seed_for(self.vision_tower_name))
-        logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
-        self.vision_tower = ConvNeXtTrunk(cfg, dtype).load_canonical(ConvNeXtTrunk.random_canonical(cfg, gen),
-                                                                     self._target_device())
+        ckpt = find_local_checkpoint(self.vision_tower_name)
+        if ckpt is not None:   # open_clip checkpoint (visual.trunk.* = timm ConvNeXt, clip_convnext_encoder.py:84-90) or HF ConvNextModel
+            from .weight_maps import hf_convnext_to_canonical, timm_convnext_to_canonical
+            sd = load_checkpoint_state(ckpt)
+            if any(k.startswith(("visual.trunk.", "trunk.", "stem.")) for k in sd):
+                canon = timm_convnext_to_canonical({k: v for k, v in sd.items() if not k.startswith("text.")}, cfg.depths)
+            else:
+                canon = hf_convnext_to_canonical(sd, cfg.depths)
+            logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
+        else:
+            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
+            canon = ConvNeXtTrunk.random_canonical(cfg, gen)
+        self.vision_tower = ConvNeXtTrunk(cfg, dtype).load_canonical(canon, self._target_device())
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size), height=self._image_size,
                                                 width=self._image_size)
         self.is_loaded = True

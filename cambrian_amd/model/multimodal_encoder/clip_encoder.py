@@ -5,7 +5,7 @@ from types import SimpleNamespace
 
 import torch
 
-from .base_encoder import BaseVisionTower, ProcessorWrapper, SimpleImageTransform, logger
+from .base_encoder import find_local_checkpoint, load_checkpoint_state, BaseVisionTower, ProcessorWrapper, SimpleImageTransform, logger
 from .vit import ViTConfig, ViTTrunk, resample_tokens
 
 # architecture table (no network: the HF config.json files cannot be fetched)
@@ -66,8 +66,17 @@ class ClipVisionTower(BaseVisionTower):
         cfg = self._vit_config()
         dtype = getattr(self, "_compute_dtype", torch.bfloat16)
         gen = torch.Generator(device=self._target_device()).manual_seed(self._seed_for(self.vision_tower_name))
-        logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
-        self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(ViTTrunk.random_canonical(cfg, gen), self._target_device())
+        ckpt = find_local_checkpoint(self.vision_tower_name)
+        if ckpt is not None:   # HF CLIPVisionModel / CLIPModel checkpoint (clip_encoder.py:47)
+            from .weight_maps import hf_clip_to_canonical
+            sd = {k[len("vision_model."):] if k.startswith("vision_model.") else k: v
+                  for k, v in load_checkpoint_state(ckpt).items() if not k.startswith(("text_model.", "text_projection", "logit_scale"))}
+            canon = hf_clip_to_canonical(sd, cfg.run_layers or cfg.num_layers)
+            logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
+        else:
+            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
+            canon = ViTTrunk.random_canonical(cfg, gen)
+        self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(canon, self._target_device())
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size), height=self._image_size,
                                                 width=self._image_size)
         self.is_loaded = True

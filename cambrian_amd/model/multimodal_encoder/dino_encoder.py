@@ -7,7 +7,8 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from .base_encoder import BaseVisionTower, ProcessorWrapper, SimpleImageTransform, logger
+from .base_encoder import (BaseVisionTower, ProcessorWrapper, SimpleImageTransform, find_local_checkpoint,
+                           load_checkpoint_state, logger)
 from .vit import ViTConfig, ViTTrunk, resample_tokens
 
 IMAGENET_MEAN, IMAGENET_STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
@@ -88,8 +89,14 @@ class DinoVisionTower(BaseVisionTower):
                         final_ln=True, layerscale=True, patch_bias=True, **a)
         dtype = getattr(self, "_compute_dtype", torch.bfloat16)
         gen = torch.Generator(device=self._target_device()).manual_seed(self._seed_for(self.vision_tower_name))
-        logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
-        canon = ViTTrunk.random_canonical(native, gen)
+        ckpt = find_local_checkpoint(self.vision_tower_name)
+        if ckpt is not None:   # HF Dinov2Model checkpoint (dino_encoder.py:81)
+            from .weight_maps import hf_dinov2_to_canonical
+            canon = hf_dinov2_to_canonical(load_checkpoint_state(ckpt), native.num_layers, native.act == "swiglu")
+            logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
+        else:
+            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
+            canon = ViTTrunk.random_canonical(native, gen)
         canon["pos"] = interpolate_pos_encoding(canon["pos"], run.grid)  # 37x37 -> e.g. 27x27 at 378 px
         self.vision_tower = ViTTrunk(run, dtype).load_canonical(canon, self._target_device())
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, IMAGENET_MEAN, IMAGENET_STD),

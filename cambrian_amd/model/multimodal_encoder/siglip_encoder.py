@@ -5,7 +5,8 @@ from types import SimpleNamespace
 
 import torch
 
-from .base_encoder import BaseVisionTower, ProcessorWrapper, SimpleImageTransform, logger
+from .base_encoder import (BaseVisionTower, ProcessorWrapper, SimpleImageTransform, find_local_checkpoint,
+                           load_checkpoint_state, logger)
 from .clip_encoder import ClipVisionTower
 from .vit import ViTConfig, ViTTrunk
 
@@ -74,8 +75,21 @@ class SiglipVisionTower(ClipVisionTower):
         cfg = self._vit_config()
         dtype = getattr(self, "_compute_dtype", torch.bfloat16)
         gen = torch.Generator(device=self._target_device()).manual_seed(self._seed_for(self.vision_tower_name))
-        logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
-        self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(ViTTrunk.random_canonical(cfg, gen), self._target_device())
+        ckpt = find_local_checkpoint(self.vision_tower_name)
+        if ckpt is not None:   # open_clip checkpoint (visual.trunk.* = timm ViT, siglip_encoder.py:53-56) or HF SiglipVisionModel
+            from .weight_maps import hf_siglip_to_canonical, timm_vit_to_canonical
+            sd = load_checkpoint_state(ckpt)
+            if any(k.startswith(("visual.trunk.", "trunk.")) or k == "pos_embed" for k in sd):
+                sd = {k: v for k, v in sd.items() if k.startswith(("visual.trunk.", "trunk.")) or not k.startswith(("text.", "visual."))}
+                canon = timm_vit_to_canonical(sd, cfg.num_layers)
+            else:
+                sd = {k: v for k, v in sd.items() if not k.startswith(("text_model.", "logit_"))}
+                canon = hf_siglip_to_canonical(sd, cfg.num_layers)
+            logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
+        else:
+            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
+            canon = ViTTrunk.random_canonical(cfg, gen)
+        self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(canon, self._target_device())
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, [0.5] * 3, [0.5] * 3),
                                                 height=self._image_size, width=self._image_size, image_mean=[0.5] * 3)
         self.is_loaded = True
