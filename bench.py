@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
                     "config 4's partitioning) instead of all-reduce + replicated AdamW")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--input-pipeline", action="store_true",
+                    help="feed decoded uint8 images through the GPU input pipeline (SURVEY.md §8f N3: pinned H2D + "
+                         "cmb_image_preprocess on a side stream, one batch ahead) instead of resident pixel tensors")
     ap.add_argument("--tuned-llm-gemms", action="store_true",
                     help="load the pre-tuned TunableOp table for the LLM's hipBLASLt GEMMs (cambrian_amd/train/llm_gemm_tuning.py); "
                          "measured neutral in the step (the default heuristic's picks are as fast under sustained load), so off")
@@ -180,7 +183,22 @@ def main():
               image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
               image_sizes=batch["image_sizes"])
 
+    feed = None
+    if args.input_pipeline:
+        import itertools
+        import numpy as np
+        from cambrian_amd.train.image_pipeline import DevicePrefetcher, GpuImagePreprocessor
+        rng = np.random.default_rng(1234 + rank)
+        sides = (512, 640, 336, 800, 1024, 448, 720, 600)     # square sources: same token layout as the resident case
+        host = [dict(raw_images=[rng.integers(0, 256, (sides[(i + k) % 8], sides[(i + k) % 8], 3), dtype=np.uint8)
+                                 for i in range(B)]) for k in range(2)]
+        pre = GpuImagePreprocessor([t.image_processor for t in model.get_model().get_vision_tower_aux_list()], dev,
+                                   torch.bfloat16)
+        feed = DevicePrefetcher(itertools.cycle(host), pre)
+
     def step():
+        if feed is not None:
+            kw["images"] = next(feed)["images"]
         out = model(**kw)
         out.loss.backward()
         if sync is not None:
@@ -217,7 +235,9 @@ def main():
             "metric": "train images/sec (fwd+bwd) Cambrian-8B 4-tower SVA, 576 vis-tok",
             "value": B * world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic" + (" uint8 images through the GPU input pipeline (H2D + resample inside the timed region)"
+                                   if args.input_pipeline else ""),
             "config": {"workload": "BASELINE configs[2]: 4-tower (SigLIP-SO400M@384 + CLIP-L@336 + DINOv2-g@378 + "
                                    "ConvNeXt-XXL@1024) + SVA (3 connector + 10 in-LLM layers) into random-init "
                                    "Llama-3-8B, 576 visual + 24 newline tokens in a 2048-token sequence, pre-training "

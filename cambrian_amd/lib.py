@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcambrian_amd.so")
 
 BF16, F32 = 0, 1
+F16 = 2   # output type of cmb_image_preprocess only
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf": ACT_GELU_ERF,
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
@@ -67,6 +68,16 @@ class SvaDesc(C.Structure):
     ]
 
 
+class ImageJob(C.Structure):
+    """cmb_image_job (include/cambrian_amd.h): one (sample, tower) unit of the image pre-processing launch."""
+    _fields_ = [
+        ("src_off", C.c_int64), ("tmp_off", C.c_int64), ("dst_off", C.c_int64),
+        ("w", C.c_int32), ("h", C.c_int32), ("side", C.c_int32), ("off_x", C.c_int32), ("off_y", C.c_int32),
+        ("out_side", C.c_int32), ("ksize", C.c_int32), ("coef_off", C.c_int32), ("bounds_off", C.c_int32),
+        ("lut_off", C.c_int32), ("background", C.c_uint32), ("reserved", C.c_int32),
+    ]
+
+
 # symbol -> (restype, argtypes); every symbol of include/cambrian_amd.h must be listed here
 # (tests/test_abi.py cross-checks this table against the header).
 _i32, _i64, _f, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -108,6 +119,8 @@ SIGNATURES = {
     "cmb_flash_attn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f,
                                      _p, _p, _p, _p, _p]),
     "cmb_swiglu_bwd": (C.c_int, [C.c_int, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
+    "cmb_resize_coeffs": (C.c_int, [_i32, _i32, _p, _p]),
+    "cmb_image_preprocess": (C.c_int, [_p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),
     "cmb_copy_rows": (C.c_int, [C.c_int, _p, C.POINTER(RowMap), _p, C.POINTER(RowMap), _i64, _i64, _p]),
 }
 

@@ -35,18 +35,23 @@ class ProcessorWrapper:
 
 class SimpleImageTransform:
     """Resize (bicubic) to size x size and normalise: the offline stand-in for CLIPImageProcessor / the
-    open_clip transform (no network to fetch their configs).  Pre-processing is CPU work outside the hot path
-    (SURVEY.md §2 row 15)."""
+    open_clip transform (no network to fetch their configs).  ``flavour`` names whose float arithmetic the pointwise
+    stage follows — 'hf' (rescale by 1/255 in float64 -> float32, then (x - mean) / std: CLIP, DINOv2) or
+    'torchvision' (ToTensor float32 / 255, Normalize: SigLIP, ConvNeXt).  This is the per-sample CPU route of the
+    reference (train_fsdp.py:1004-1008); the step-boundary route that does the same arithmetic for a whole batch on
+    the GPU is cambrian_amd/train/image_pipeline.py, which reads ``mean`` / ``std`` / ``flavour`` from here."""
 
-    def __init__(self, size: int, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD):
-        self.size, self.mean, self.std = size, mean, std
+    def __init__(self, size: int, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD, flavour: str = "torchvision"):
+        self.size, self.mean, self.std, self.flavour = size, mean, std, flavour
 
     def __call__(self, image):
         import numpy as np
         img = image.convert("RGB").resize((self.size, self.size), resample=3)
-        x = torch.from_numpy(np.asarray(img).copy()).float().div_(255.0).permute(2, 0, 1)
-        mean = torch.tensor(self.mean).view(3, 1, 1)
-        std = torch.tensor(self.std).view(3, 1, 1)
+        u = np.asarray(img)
+        x = (u * (1 / 255)).astype(np.float32) if self.flavour == "hf" else u.astype(np.float32) / np.float32(255)
+        x = torch.from_numpy(x).permute(2, 0, 1)
+        mean = torch.tensor(self.mean, dtype=torch.float32).view(3, 1, 1)
+        std = torch.tensor(self.std, dtype=torch.float32).view(3, 1, 1)
         return (x - mean) / std
 
 

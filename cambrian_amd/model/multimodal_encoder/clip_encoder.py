@@ -77,7 +77,7 @@ class ClipVisionTower(BaseVisionTower):
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
             canon = ViTTrunk.random_canonical(cfg, gen)
         self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(canon, self._target_device())
-        self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size), height=self._image_size,
+        self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, flavour="hf"), height=self._image_size,
                                                 width=self._image_size)
         self.is_loaded = True
 

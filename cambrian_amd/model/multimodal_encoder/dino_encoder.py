@@ -99,7 +99,7 @@ class DinoVisionTower(BaseVisionTower):
             canon = ViTTrunk.random_canonical(native, gen)
         canon["pos"] = interpolate_pos_encoding(canon["pos"], run.grid)  # 37x37 -> e.g. 27x27 at 378 px
         self.vision_tower = ViTTrunk(run, dtype).load_canonical(canon, self._target_device())
-        self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, IMAGENET_MEAN, IMAGENET_STD),
+        self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, IMAGENET_MEAN, IMAGENET_STD, flavour="hf"),
                                                 height=self._image_size, width=self._image_size,
                                                 image_mean=IMAGENET_MEAN)
         self.is_loaded = True

@@ -127,7 +127,12 @@ class DataCollatorForSupervisedDataset:
         ids, lab, att, pos, aux = prepare_multimodal_data(input_ids, labels, attention_mask, image_sizes,
                                                           self.image_token_len, self.image_aux_token_len_list, max_length)
         batch = dict(input_ids=ids, labels=lab, attention_mask=att, position_ids=pos, image_aux_attention_masks_list=aux)
-        if "image_aux_list" in instances[0]:
+        if "image_raw" in instances[0]:
+            # step-boundary route: the dataset only decodes; the uint8 pixels travel as they are
+            # and train/image_pipeline.py produces the per-tower tensors on the GPU (DevicePrefetcher)
+            batch["raw_images"] = [i["image_raw"] for i in instances]
+            batch["image_sizes"] = image_sizes
+        elif "image_aux_list" in instances[0]:
             per_tower = [list(x) for x in zip(*[i["image_aux_list"] for i in instances])]
             if all(x is not None and x.shape == per_tower[0][0].shape for x in per_tower[0]):
                 batch["images"] = [torch.stack(x) for x in per_tower]

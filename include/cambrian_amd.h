@@ -303,6 +303,49 @@ int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* 
 int cmb_swiglu_bwd(int dtype, const void* dh, int64_t lddh, const void* g, int64_t ldg, const void* u, int64_t ldu,
                    int64_t rows, int64_t D, void* dg, int64_t lddg, void* du, int64_t lddu, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Image pre-processing on the step boundary
+ * replaces, per sample and per tower:  train_fsdp.py:985-1008 / mm_utils.py:153-165,183-201
+ *     image_aux = expand2square(image, tuple(int(x*255) for x in processor.image_mean)).resize((R, R))
+ *     image_aux = processor.preprocess(image_aux, return_tensors='pt')['pixel_values'][0]
+ * i.e. letter-box to a square with the tower's mean colour, Pillow's two-pass fixed-point bicubic
+ * resample (libImaging/Resample.c, 22-bit coefficients, uint8 intermediate), then the processor's pointwise
+ * rescale + normalise, emitted planar [3,R,R].  Integer work: results are bit-identical to Pillow's; the
+ * pointwise stage is a caller-built table lut[c][level] (fp32), so it reproduces whichever processor flavour
+ * (HF rescale/normalize or torchvision ToTensor/Normalize) the tower uses exactly.
+ * One launch pair handles a whole batch x all towers through a job table.
+ * ---------------------------------------------------------------------------------------- */
+enum { CMB_F16 = 2 };          /* extra output element type of cmb_image_preprocess only */
+
+typedef struct cmb_image_job {
+  int64_t src_off;     /* byte offset of this sample's uint8 [h, w, 3] pixels in `src` */
+  int64_t tmp_off;     /* byte offset (multiple of 4) of this job's scratch planes [3, side, pitch] in `tmp`,
+                          pitch = (out_side + 3) & ~3; unused when ksize == 0 */
+  int64_t dst_off;     /* element offset of this job's [3, out_side, out_side] output in `dst` */
+  int32_t w, h;        /* source size */
+  int32_t side;        /* max(w, h): the letter-boxed square (mm_utils.py:153-165) */
+  int32_t off_x, off_y;/* where the source sits inside the square: ((side-w)/2, 0) or (0, (side-h)/2) */
+  int32_t out_side;    /* R */
+  int32_t ksize;       /* taps per output; 0 = side == out_side, Image.resize returns a copy */
+  int32_t coef_off;    /* int32 offset of this job's tap-major coefficients [ksize, out_side] in `coefs` */
+  int32_t bounds_off;  /* int32 offset of this job's [out_side, 2] (first, count) in `bounds` */
+  int32_t lut_off;     /* element offset of this tower's fp32 [3, 256] table in `lut` */
+  uint32_t background; /* r | g << 8 | b << 16 */
+  int32_t reserved;
+} cmb_image_job;
+
+/* HOST function (no device work): taps of Pillow's bicubic resample of `in_size` -> `out_size` samples over the
+ * full box.  Returns ksize = 2*ceil(2*max(in/out,1)) + 1, or a negative status.  With non-null outputs fills
+ * bounds [out_size, 2] = (first, count) and coefs [ksize, out_size] (tap-major, 22-bit fixed point, zero beyond
+ * count).  Follows precompute_coeffs + normalize_coeffs_8bpc; double precision, no contraction. */
+int cmb_resize_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* coefs);
+/* Runs the horizontal pass (src -> tmp) and the vertical + table pass (tmp -> dst) for n_jobs jobs.
+ * jobs_dev / jobs_host are the same table in device and host memory (the host copy sizes the grids).
+ * out_dtype: CMB_BF16 | CMB_F32 | CMB_F16 (table value rounded to nearest even). */
+int cmb_image_preprocess(const cmb_image_job* jobs_dev, const cmb_image_job* jobs_host, int32_t n_jobs,
+                         const uint8_t* src, const int32_t* bounds, const int32_t* coefs, const float* lut,
+                         int32_t out_dtype, uint8_t* tmp, void* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
