@@ -51,6 +51,16 @@ def prepare_inputs_static(p: Dict[str, torch.Tensor], cfg, input_ids: torch.Tens
     Returns (inputs_embeds [B,S,H], kv_final list (window-major), mask_final list, ctx_final)."""
     bs = tower_feats[0].shape[0]
     side = int(cfg.image_token_len ** 0.5)
+    if getattr(cfg, "mm_projector_type", "sva") != "sva":
+        # :407-411 non-SVA branch (BASELINE configs[0]): channel-concat of the tower features -> mlpNx_gelu projector
+        # (multimodal_projector/builder.py:60-67, nn.Sequential keys 0, 2, ...), no in-LLM lists
+        img = torch.cat(list(tower_feats), -1)
+        depth = int(cfg.mm_projector_type[len("mlp")])
+        for d in range(depth):
+            if d:
+                img = O.gelu_erf(img)
+            img = img @ p[f"mm_projector.{2 * d}.weight"].T + p[f"mm_projector.{2 * d}.bias"]
+        return _newline_and_splice(p, img, bs, side, input_ids, embed_table), None, None, None
     feats = [mlp_projector(p, f"mm_projector_aux_{i}.", f, True) for i, f in enumerate(tower_feats)]   # :372-379
     ctx = feats[0].mean(1).view(bs, 1, 1, -1)                                                        # :377
     finals = []
@@ -71,6 +81,10 @@ def prepare_inputs_static(p: Dict[str, torch.Tensor], cfg, input_ids: torch.Tens
     ctx_final = ctx.expand(-1, side * side, 1, -1).flatten(0, 1)
     img = torch.cat(finals, -1)                                                                      # :410
     img = mlp_projector(p, "mm_projector.", img, False)                                              # :411
+    return _newline_and_splice(p, img, bs, side, input_ids, embed_table), kv_final, mask_final, ctx_final
+
+
+def _newline_and_splice(p, img, bs, side, input_ids, embed_table):
     img = img.view(bs, side, side, -1)                                                               # :413-420
     img = torch.cat([img, p["image_newline"][None, None, None, :].expand(bs, side, 1, -1)], dim=2).flatten(1, 2)
     emb = embed_table[torch.where(input_ids == IMAGE_TOKEN_INDEX, 0, input_ids)]                    # :460-461
@@ -83,7 +97,7 @@ def prepare_inputs_static(p: Dict[str, torch.Tensor], cfg, input_ids: torch.Tens
         assert len(idx) == 1, "the collator guarantees exactly one image token per row (train_fsdp.py:1100-1101)"
         pos = idx[0]
         rows.append(torch.cat([emb[b, :pos], img[b], emb[b, pos + img.shape[1]:]]))
-    return torch.stack(rows), kv_final, mask_final, ctx_final
+    return torch.stack(rows)
 
 
 # -------------------------------------------------------------------------------------------- collator

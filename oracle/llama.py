@@ -67,12 +67,19 @@ def sva_hook(hidden: torch.Tensor, sampler_params: Dict[str, torch.Tensor], pref
 
 def decoder_forward(p: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor, position_ids: torch.Tensor,
                     attention_mask: Optional[torch.Tensor] = None, hook=None) -> torch.Tensor:
-    """Plain Llama decoder with HF key names (model.layers.{i}....); ``hook(i, hidden)`` runs after layer i."""
+    """Plain Llama decoder with HF key names (model.layers.{i}....); ``hook(i, hidden)`` runs after layer i.
+    Phi-3 (phi3/modeling_phi3.py): same arithmetic with packed ``qkv_proj`` (q | k | v rows, :397-402) and
+    ``gate_up_proj`` (gate | up rows, :303-308) weights, and, with ``cfg.sliding_window`` set, keys further than the
+    window behind the query masked (eager mask of :1180-1186: visible iff 0 <= i - j <= window)."""
     B, S, H = inputs_embeds.shape
     nh, nkv = cfg.num_attention_heads, cfg.num_key_value_heads
     hd = H // nh
     cos, sin = rope_cos_sin(position_ids, hd, cfg.rope_theta)
     causal = torch.ones(S, S, dtype=torch.bool).tril_()
+    window = getattr(cfg, "sliding_window", None)
+    if window is not None:
+        i = torch.arange(S)
+        causal = causal & ((i[:, None] - i[None, :]) <= window)
     mask = causal[None, None]
     if attention_mask is not None:
         mask = (mask & attention_mask.bool()[:, None, None, :]) | torch.eye(S, dtype=torch.bool)[None, None]
@@ -80,9 +87,13 @@ def decoder_forward(p: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor
     for i in range(cfg.num_hidden_layers):
         pre = f"model.layers.{i}."
         h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg.rms_norm_eps)
-        q = (h @ p[pre + "self_attn.q_proj.weight"].T).view(B, S, nh, hd).transpose(1, 2)
-        k = (h @ p[pre + "self_attn.k_proj.weight"].T).view(B, S, nkv, hd).transpose(1, 2)
-        v = (h @ p[pre + "self_attn.v_proj.weight"].T).view(B, S, nkv, hd).transpose(1, 2)
+        if pre + "self_attn.qkv_proj.weight" in p:
+            wq, wk, wv = torch.split(p[pre + "self_attn.qkv_proj.weight"], [nh * hd, nkv * hd, nkv * hd], 0)
+        else:
+            wq, wk, wv = (p[pre + f"self_attn.{n}_proj.weight"] for n in "qkv")
+        q = (h @ wq.T).view(B, S, nh, hd).transpose(1, 2)
+        k = (h @ wk.T).view(B, S, nkv, hd).transpose(1, 2)
+        v = (h @ wv.T).view(B, S, nkv, hd).transpose(1, 2)
         q, k = apply_rope(q, k, cos, sin)
         k = k.repeat_interleave(nh // nkv, dim=1)
         v = v.repeat_interleave(nh // nkv, dim=1)
@@ -91,7 +102,11 @@ def decoder_forward(p: Dict[str, torch.Tensor], cfg, inputs_embeds: torch.Tensor
         a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, H)
         x = x + a @ p[pre + "self_attn.o_proj.weight"].T
         h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
-        x = x + (F.silu(h @ p[pre + "mlp.gate_proj.weight"].T) * (h @ p[pre + "mlp.up_proj.weight"].T)) @ p[pre + "mlp.down_proj.weight"].T
+        if pre + "mlp.gate_up_proj.weight" in p:
+            wg, wu = p[pre + "mlp.gate_up_proj.weight"].chunk(2, 0)
+        else:
+            wg, wu = p[pre + "mlp.gate_proj.weight"], p[pre + "mlp.up_proj.weight"]
+        x = x + (F.silu(h @ wg.T) * (h @ wu.T)) @ p[pre + "mlp.down_proj.weight"].T
         if hook is not None:
             x = hook(i, x)
     return rms_norm(x, p["model.norm.weight"], cfg.rms_norm_eps)

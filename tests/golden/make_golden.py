@@ -486,6 +486,183 @@ def golden_arch_dynamic():
     print("arch_dynamic_small.pt written: embeds", tuple(out[4].shape), "final sizes", out[8])
 
 
+def load_ref_phi3():
+    """The reference's vendored Phi-3 (cambrian/model/language_model/phi3/) by path, with its static (XLA) branch on."""
+    load_ref_arch()
+    name = "cambrian.model.language_model.phi3"
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.__path__ = [f"{REF}/cambrian/model/language_model/phi3"]
+        sys.modules[name] = m
+    mods = {}
+    for part in ("configuration_phi3", "modeling_phi3"):
+        full = f"{name}.{part}"
+        if full not in sys.modules:
+            spec = importlib.util.spec_from_file_location(full, f"{REF}/cambrian/model/language_model/phi3/{part}.py")
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[full] = mod
+            spec.loader.exec_module(mod)
+        mods[part] = sys.modules[full]
+    mods["modeling_phi3"].IS_XLA_AVAILABLE = True
+    return mods["configuration_phi3"], mods["modeling_phi3"]
+
+
+def golden_config0():
+    """BASELINE configs[0] (one CLIP tower + mlp2x_gelu projector into Phi-3), small:
+    (a) the real prepare_inputs_labels_for_multimodal, static branch, mm_projector_type = 'mlp2x_gelu'
+        (cambrian_arch.py:79-87 construction, :407-420 concat -> projector -> newline, :457-490 splice), fake tower;
+    (b) the reference's vendored Phi3ForCausalLM (phi3/modeling_phi3.py) on CPU: bare decoder logits, the same with a
+        sliding window shorter than the sequence (eager mask, :1180-1186), and with the in-LLM SVA hook
+        (:1221-1260, static branch) driven by real VisionTokenSampler layers."""
+    import torch.nn as nn
+    A = load_ref_arch()
+    ns = load_ref_collator()
+    torch.manual_seed(31337)
+    H, side, B, S, V, tdim = 64, 4, 2, 48, 60, 40
+
+    class FakeTower(nn.Module):
+        def __init__(self, hidden, tokens):
+            super().__init__()
+            self.hidden_size, self.tokens, self.is_loaded = hidden, tokens, True
+            self.out = None
+
+        def load_model(self):
+            pass
+
+        def forward(self, images):
+            return self.out
+
+    towers = [FakeTower(tdim, side * side)]
+
+    class Cfg:
+        pass
+
+    cfg = Cfg()
+    cfg.hidden_size = H
+    cfg.mm_vision_tower_aux_list = ["clip"]
+    cfg.mm_vision_tower_aux_token_len_list = [side * side]
+    cfg.mm_projector_type = "mlp2x_gelu"
+    cfg.image_token_len = side * side
+    cfg.query_num_list = [side * side]
+    cfg.connector_only = True
+    cfg._fake_towers = towers
+
+    class Base(nn.Module):
+        def __init__(self, config):
+            super().__init__()
+            self.config = config
+            self.embed_tokens = nn.Embedding(V, H)
+
+        @property
+        def dtype(self):
+            return torch.float32
+
+    class Model(A.CambrianMetaModel, Base):
+        pass
+
+    class LM(nn.Module, A.CambrianMetaForCausalLM):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg
+            self.model = Model(cfg)
+
+        def get_model(self):
+            return self.model
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    lm = LM()
+    with torch.no_grad():
+        lm.model.image_newline.copy_(torch.randn(H) / H ** 0.5)
+    ids = torch.randint(1, V, (B, 28))
+    labels = ids.clone()
+    att = torch.ones(B, 28, dtype=torch.bool)
+    ids[0, 3] = -200
+    ids[1, 9] = -200
+    sizes = [(224, 224), (224, 100)]
+    new_ids, new_lab, new_att, new_pos, aux_masks = ns["prepare_multimodal_data"](ids, labels, att, sizes, side * side,
+                                                                               [side * side], S)
+    feat = torch.randn(B, side * side, tdim, requires_grad=True)
+    towers[0].out = feat
+    out = lm.prepare_inputs_labels_for_multimodal(new_ids, new_pos, new_att, None, new_lab, [torch.zeros(B, 3, 8, 8)],
+                                                  aux_masks, sizes)
+    emb = out[4]
+    assert out[6] is None and out[7] is None and out[9] is None
+    w = torch.randn_like(emb)
+    (emb * w).sum().backward()
+    fx = {"arch": dict(cfg=dict(H=H, side=side, B=B, S=S, V=V, tower_dim=tdim),
+                       state={k: v.detach().clone() for k, v in lm.model.state_dict().items()},
+                       ids=new_ids, pos=new_pos, att=new_att, labels=new_lab, sizes=sizes, feat=feat.detach().clone(),
+                       embeds=emb.detach().clone(), final_size=out[8], w=w, dfeat=feat.grad.clone(),
+                       dparams={n: p_.grad.clone() for n, p_ in lm.model.named_parameters() if p_.grad is not None})}
+
+    # ---- (b) vendored Phi-3 -----------------------------------------------------------------------------------
+    C, M = load_ref_phi3()
+    vs = load_ref_vision_sampler()
+    geo = dict(vocab_size=V, hidden_size=H, intermediate_size=96, num_hidden_layers=3, num_attention_heads=2,
+               num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=128)
+
+    def make(sliding_window, connector_only):
+        c = C.Phi3Config(original_max_position_embeddings=128, sliding_window=sliding_window, pad_token_id=0,
+                         bos_token_id=1, eos_token_id=2, attn_implementation="eager", **geo)
+        c.rope_scaling = None            # transformers 5.x turns it into a dict the 4.37-era _init_rope cannot read
+        c.connector_only = connector_only
+        return c
+
+    torch.manual_seed(99)
+    bare = M.Phi3ForCausalLM(make(None, True)).eval()
+    state = {k: v.detach().clone() for k, v in bare.state_dict().items()}
+    S2 = 24
+    pids = torch.randint(1, V, (B, S2))
+    pos = torch.arange(S2)[None].expand(B, -1).contiguous()
+    with torch.no_grad():
+        logits = bare(input_ids=pids, position_ids=pos, use_cache=False, return_dict=True).logits
+    win = M.Phi3ForCausalLM(make(8, True)).eval()
+    win.load_state_dict(state)
+    with torch.no_grad():
+        logits_win = win(input_ids=pids, position_ids=pos, use_cache=False, return_dict=True).logits
+    assert (logits - logits_win).abs().max() > 1e-4   # the window really bites
+
+    vh, p0 = 32, 2
+    hk = make(None, False)
+    hk.image_token_len, hk.image_position = side * side, p0
+    hk.start_of_vision_sampler_layers, hk.stride_of_vision_sampler_layers = 0, 2
+    hooked = M.Phi3ForCausalLM(hk).eval()
+    hooked.load_state_dict(state)
+    samplers = nn.ModuleList([vs.VisionTokenSampler(H, vh, [vh, vh], [1, 2], vh, 1).float() for _ in range(2)])
+    hooked.model.vision_sampler_layers = samplers
+    kvs = [torch.randn(B * side * side, s * s, vh) for s in (1, 2)]
+    masks = [torch.ones(B * side * side, s * s, dtype=torch.bool) for s in (1, 2)]
+    masks[1][5, 1:] = False
+    ctx = torch.randn(B * side * side, 1, vh)
+    emb2 = torch.randn(B, S2, H)
+    # :1241 `latent_query.view(bs*latent_query_num, 1, -1)` is applied to a non-contiguous slice: legal on XLA (functional
+    # views), a RuntimeError on eager CPU torch.  Same values with reshape — patched in for the duration of the call.
+    orig_view = torch.Tensor.view
+
+    def lenient_view(self, *shape, **kw):
+        try:
+            return orig_view(self, *shape, **kw)
+        except RuntimeError:
+            return self.reshape(*shape)
+    torch.Tensor.view = lenient_view
+    with torch.no_grad():
+        logits_hook = hooked(inputs_embeds=emb2, position_ids=pos, use_cache=False, return_dict=True,
+                             vision_tower_aux_feature_list=kvs, vision_tower_aux_attention_masks_list=masks,
+                             final_vision_feature_size=[(side, side)] * B, global_context_feature=ctx).logits
+        logits_nohook = hooked(inputs_embeds=emb2, position_ids=pos, use_cache=False, return_dict=True).logits
+    torch.Tensor.view = orig_view
+    assert (logits_hook - logits_nohook).abs().max() > 1e-3
+    fx["phi3"] = dict(cfg=dict(geo, vh=vh, side=side, p0=p0, start=0, stride=2), state=state, ids=pids, pos=pos,
+                      logits=logits, sliding_window=8, logits_window=logits_win,
+                      sampler_state={k: v.detach().clone() for k, v in samplers.state_dict().items()},
+                      embeds=emb2, kvs=kvs, masks=masks, ctx=ctx, logits_hook=logits_hook)
+    torch.save(fx, f"{OUT}/config0_small.pt")
+    print("config0_small.pt written; arch dparams:", sorted(fx["arch"]["dparams"].keys()))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sva"]
     for w in which:

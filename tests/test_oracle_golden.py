@@ -224,3 +224,51 @@ def test_hook_oracle_dynamic_matches_reference_lines():
                                  fx["ctx_final"], fx["kv_final"], fx["mask_final"])
     assert torch.allclose(out, hk["out"], atol=2e-6, rtol=1e-5)
     assert not torch.equal(out, hk["hidden"])
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[0]
+def test_arch_oracle_mlp_projector_branch_matches_reference():
+    """cambrian_arch.py:79-87,407-420,457-490: one tower + mlp2x_gelu projector (no SVA), forward and gradients."""
+    from oracle import arch
+    fx = _load("config0_small.pt")["arch"]
+    c = fx["cfg"]
+    cfg = _NS(image_token_len=c["side"] ** 2, query_num_list=[c["side"] ** 2], mm_projector_type="mlp2x_gelu")
+    p = {k: v.clone().requires_grad_() for k, v in fx["state"].items()}
+    feat = fx["feat"].clone().requires_grad_()
+    emb, kv, masks, ctx = arch.prepare_inputs_static(p, cfg, fx["ids"], [feat], None, p["embed_tokens.weight"])
+    assert kv is None and masks is None and ctx is None
+    assert torch.allclose(emb, fx["embeds"], atol=2e-6, rtol=1e-5)
+    (emb * fx["w"]).sum().backward()
+    assert torch.allclose(feat.grad, fx["dfeat"], atol=1e-5, rtol=1e-4)
+    for name, g in fx["dparams"].items():
+        if name != "embed_tokens.weight":
+            assert torch.allclose(p[name].grad, g, atol=2e-5, rtol=1e-4), name
+
+
+def test_decoder_oracle_matches_reference_phi3():
+    """The reference's vendored Phi3ForCausalLM (phi3/modeling_phi3.py) run on CPU: packed qkv / gate_up weights, the
+    sliding-window mask, and the in-LLM SVA hook twin (:1221-1260) with real VisionTokenSampler layers."""
+    from oracle import llama
+    fx = _load("config0_small.pt")["phi3"]
+    c = fx["cfg"]
+    keys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+            "num_key_value_heads", "rms_norm_eps", "rope_theta")
+    p = fx["state"]
+    emb = p["model.embed_tokens.weight"][fx["ids"]]
+    cfg = _NS(**{k: c[k] for k in keys})
+    _, logits = llama.lm_loss(llama.decoder_forward(p, cfg, emb, fx["pos"]), p["lm_head.weight"], fx["ids"])
+    assert torch.allclose(logits, fx["logits"], atol=2e-5, rtol=1e-4)
+    cfg_w = _NS(sliding_window=fx["sliding_window"], **{k: c[k] for k in keys})
+    _, logits_w = llama.lm_loss(llama.decoder_forward(p, cfg_w, emb, fx["pos"]), p["lm_head.weight"], fx["ids"])
+    assert torch.allclose(logits_w, fx["logits_window"], atol=2e-5, rtol=1e-4)
+    assert not torch.allclose(logits_w, logits, atol=1e-4)
+    hooks = {c["start"] + k * c["stride"]: k for k in range(2)}
+
+    def hook(i, x):
+        if i not in hooks:
+            return x
+        return llama.sva_hook(x, fx["sampler_state"], f"{hooks[i]}.", c["p0"], c["side"] ** 2, fx["ctx"], fx["kvs"],
+                              fx["masks"])
+    _, logits_h = llama.lm_loss(llama.decoder_forward(p, cfg, fx["embeds"], fx["pos"], None, hook), p["lm_head.weight"],
+                                fx["ids"])
+    assert torch.allclose(logits_h, fx["logits_hook"], atol=3e-5, rtol=1e-4)
