@@ -162,14 +162,17 @@ class LlamaDecoderLayer(nn.Module):
 
 
 class LlamaBackbone(nn.Module):
-    """HF ``LlamaModel`` parameter layout (embed_tokens / layers / norm), minimal forward."""
+    """HF ``LlamaModel`` parameter layout (embed_tokens / layers / norm), minimal forward.  ``layer_class`` is the
+    decoder block; cambrian_phi3.py swaps in the Phi-3 block (packed qkv_proj / gate_up_proj parameters)."""
+    layer_class = None  # set below, once LlamaDecoderLayer's own class statement has run
 
     def __init__(self, config, device=None, llm_dtype=torch.bfloat16):
         super().__init__()
         self.config = config
         self.llm_dtype = llm_dtype
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, device=device, dtype=llm_dtype)
-        self.layers = nn.ModuleList([LlamaDecoderLayer(config, device, llm_dtype) for _ in range(config.num_hidden_layers)])
+        block = type(self).layer_class or LlamaDecoderLayer
+        self.layers = nn.ModuleList([block(config, device, llm_dtype) for _ in range(config.num_hidden_layers)])
         self.norm = HipRMSNorm(config.hidden_size, config.rms_norm_eps, device, llm_dtype)
 
     @property
@@ -200,11 +203,18 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
         hd = self.layers[0].self_attn.hd
         cos, sin = ops.rope_table(position_ids, hd, float(getattr(cfg, "rope_theta", 10000.0)))
         attn_mask = None
-        if attention_mask is not None:
+        window = getattr(cfg, "sliding_window", None)
+        if window is not None and S <= window + 1:
+            window = None                      # every key is within reach: plain causal attention
+        if attention_mask is not None or window is not None:
             causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril_()
-            attn_mask = causal[None, None] & attention_mask.to(torch.bool)[:, None, None, :]
-            # a fully masked query row would be NaN in SDPA; padded rows attend to themselves (their loss is ignored)
-            attn_mask = attn_mask | torch.eye(S, dtype=torch.bool, device=dev)[None, None]
+            if window is not None:             # Phi-3 eager mask (phi3/modeling_phi3.py:1180-1186): 0 <= i - j <= window
+                causal = causal & ~torch.ones(S, S, dtype=torch.bool, device=dev).tril_(-(window + 1))
+            attn_mask = causal[None, None]
+            if attention_mask is not None:
+                attn_mask = attn_mask & attention_mask.to(torch.bool)[:, None, None, :]
+                # a fully masked query row would be NaN in SDPA; padded rows attend to themselves (their loss is ignored)
+                attn_mask = attn_mask | torch.eye(S, dtype=torch.bool, device=dev)[None, None]
         hidden = inputs_embeds
         hook_layers = {}
         if sva is not None and not getattr(cfg, "connector_only", True):
@@ -273,11 +283,12 @@ class _BackboneShim:
 
 class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
     config_class = CambrianConfig
+    model_class = CambrianLlamaModel
 
     def __init__(self, config, device=None, llm_dtype=torch.bfloat16):
         super().__init__()
         self.config = config
-        self.model = CambrianLlamaModel(config, device, llm_dtype)
+        self.model = type(self).model_class(config, device, llm_dtype)
         self.vocab_size = config.vocab_size
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False, device=device, dtype=llm_dtype)
 
