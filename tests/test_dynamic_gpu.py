@@ -104,8 +104,9 @@ def test_dynamic_end_to_end_logits_match_oracle(dev, monkeypatch, name, dt, tol)
     assert e < tol, f"eval-branch logits rel err {e}"
 
 
-def test_generate_cached_decode_equals_full_reforward(dev, monkeypatch):
-    model, cfg, towers = _build(dev, torch.float32, monkeypatch)
+@pytest.mark.parametrize("lm,nkv", [("llama", 2), ("phi3", 4)])
+def test_generate_cached_decode_equals_full_reforward(dev, monkeypatch, lm, nkv):
+    model, cfg, towers = _build(dev, torch.float32, monkeypatch, lm=lm, nkv=nkv)
     model.eval()
     ids, att, sizes, images = _eval_batch(dev, torch.float32, towers)
     ids, sizes, images = ids[:1], sizes[1:2], [i[1:2] for i in images]     # one wide image, no padding
