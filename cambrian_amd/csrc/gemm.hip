@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split over the waves");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   typedef typename Mfma<T>::frag_t frag_t;
+  typedef typename Mfma<T>::out_t out_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,15 +121,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p
       if (kt + 1 < nk) stage(cur ^ 1);  // async: lands while this K-step's MFMAs run
       const char* base = smem + cur * STAGE;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < Mfma<T>::KSTEPS; ++ks) {
         frag_t a[TM], b[TN];
-        const int ch = gl_frag_chunk(ks, lane);
 #pragma unroll
-        for (int t = 0; t < TM; ++t)
-          a[t] = *reinterpret_cast<const frag_t*>(base + a_off[t] + ((ch ^ a_swz[t]) << 4));
+        for (int t = 0; t < TM; ++t) a[t] = Mfma<T>::load(base + a_off[t], a_swz[t], ks, lane);
 #pragma unroll
-        for (int t = 0; t < TN; ++t)
-          b[t] = *reinterpret_cast<const frag_t*>(base + b_off[t] + ((ch ^ b_swz[t]) << 4));
+        for (int t = 0; t < TN; ++t) b[t] = Mfma<T>::load(base + b_off[t], b_swz[t], ks, lane);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -174,7 +172,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
       }
-      gemm_epilogue8<T, ACT>(p, kz, gm, gn, v);
+      gemm_epilogue8<out_t, ACT>(p, kz, gm, gn, v);
     }
   });
 }
@@ -270,7 +268,12 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   p.out_f32 = (d->out_dtype == CMB_F32);
   p.slabs = nullptr;
   p.k_per_split = p.K;
+  p.a_scale = nullptr; p.b_scale = nullptr;
   int splits = d->split_k > 1 ? d->split_k : 1;
+  if constexpr (sizeof(T) == 1) {
+    if (splits > 1) return CMB_ERR_BAD_ARG;
+    p.a_scale = d->a_scale; p.b_scale = d->b_scale;
+  }
   // every row base and leading dimension must keep 16-byte chunks aligned
   const int64_t es = sizeof(T);
   if (!cmb_aligned16(d->A) || !cmb_aligned16(d->B) || (d->ldb * es) % 16 != 0 ||
@@ -305,8 +308,8 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
       hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, p.slabs, splits,
                          p.M, p.N, p.C, p.c_map, p.alpha, p.beta);
     else
-      hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, p.slabs, splits, p.M,
-                         p.N, p.C, p.c_map, p.alpha, p.beta);
+      hipLaunchKernelGGL(splitk_reduce_kernel<typename Mfma<T>::out_t>, dim3(blocks), dim3(256), 0, s, p.slabs, splits,
+                         p.M, p.N, p.C, p.c_map, p.alpha, p.beta);
     CMB_CHECK_LAUNCH();
   }
   return CMB_OK;
@@ -327,5 +330,6 @@ extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == CMB_BF16) return gemm_dispatch<bf16_t>(d, s);
   if (d->dtype == CMB_F32) return gemm_dispatch<float>(d, s);
+  if (d->dtype == CMB_FP8_E4M3) return gemm_dispatch<fp8e4m3_t>(d, s);
   return CMB_ERR_BAD_ARG;
 }

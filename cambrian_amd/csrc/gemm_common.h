@@ -22,20 +22,57 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int k_per_split;
   float* slabs;
+  const float* a_scale;  // fp8 operands: per-row dequantisation factors (nullptr otherwise)
+  const float* b_scale;
 };
 
+// storage tag of an OCP e4m3fn operand byte (gfx950 native fp8)
+struct fp8e4m3_t { uint8_t v; };
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+// Mfma<T>: operand fragment of one 128-byte LDS tile row, the MFMA that consumes it, and the element type the
+// epilogue reads / writes (residual, pre_out, C).  ``load`` reads sub-step ks (of KSTEPS) of the swizzled row at
+// ``row`` (gemm_layout.h): 16-byte chunk 2*ks + (lane >> 5) for the 16-bit / 32-bit types, the chunk pair
+// 4*ks + 2*(lane >> 5) + {0, 1} for fp8 (32 consecutive k per lane).  A and B use the same k <-> slot map, which is all
+// a dot product needs.
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16_t> {
   typedef bf16x8_t frag_t;
+  typedef bf16_t out_t;
+  static constexpr int KSTEPS = 4;
+  static __device__ __forceinline__ frag_t load(const char* row, int swz, int ks, int lane) {
+    return *reinterpret_cast<const frag_t*>(row + ((gl_frag_chunk(ks, lane) ^ swz) << 4));
+  }
   static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
 template <> struct Mfma<float> {
   typedef f32x4_t frag_t;
+  typedef float out_t;
+  static constexpr int KSTEPS = 4;
+  static __device__ __forceinline__ frag_t load(const char* row, int swz, int ks, int lane) {
+    return *reinterpret_cast<const frag_t*>(row + ((gl_frag_chunk(ks, lane) ^ swz) << 4));
+  }
   static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<fp8e4m3_t> {
+  typedef i32x8_t frag_t;
+  typedef bf16_t out_t;
+  static constexpr int KSTEPS = 2;
+  static __device__ __forceinline__ frag_t load(const char* row, int swz, int ks, int lane) {
+    const int c0 = 4 * ks + 2 * (lane >> 5);
+    const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(row + ((c0 ^ swz) << 4));
+    const i32x4_t hi = *reinterpret_cast<const i32x4_t*>(row + (((c0 | 1) ^ swz) << 4));
+    return frag_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+  static __device__ __forceinline__ void run(const frag_t& a, const frag_t& b, f32x16_t& c) {
+    // cbsz = blgp = 0: both operands e4m3; zero scale operands select the unscaled v_mfma_f32_32x32x64_f8f6f4
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
   }
 };
 
@@ -54,6 +91,13 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
   if (p.slabs) {  // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
     Vec8<float>::store(p.slabs + ((int64_t)kz * p.M + gm) * p.N + gn, v);
     return;
+  }
+  if (p.a_scale || p.b_scale) {  // fp8 operands: undo the row-wise quantisation scales
+    const float sa = p.a_scale ? p.a_scale[gm] : 1.0f;
+    float sb[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    if (p.b_scale) load8f(p.b_scale + gn, sb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sa * sb[e];
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] *= p.alpha;

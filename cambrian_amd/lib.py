@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcambrian_amd.so")
 
 BF16, F32 = 0, 1
 F16 = 2   # output type of cmb_image_preprocess only
+FP8_E4M3 = 3   # operand type of cmb_gemm (OCP e4m3fn bytes from cmb_quantize_fp8_rows)
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf": ACT_GELU_ERF,
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
@@ -48,6 +49,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float),
         ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("tile_hint", C.c_int32),
+        ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
     ]
 
 
@@ -86,6 +88,7 @@ SIGNATURES = {
     "cmb_abi_version": (C.c_int, []),
     "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
     "cmb_gemm_tile": (C.c_int, [C.c_int, _i64, _i64, _i32, _i32]),
+    "cmb_quantize_fp8_rows": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_cast": (C.c_int, [C.c_int, _p, C.c_int, _p, _i64, _p]),

@@ -89,8 +89,9 @@ def _sva_modules(owner: nn.Module, config, vision_tower_aux_list, hidden_size: i
     image_token_len = config.image_token_len
     owner.mm_projector = HipSequential(nn.Linear(vh * n_group, hidden_size), nn.GELU(), nn.Linear(hidden_size, hidden_size))
     for aux_i, tower in enumerate(vision_tower_aux_list):
-        setattr(owner, f"mm_projector_aux_{aux_i}",
-                HipSequential(nn.Linear(tower.hidden_size, vh), nn.GELU(), nn.Linear(vh, vh), nn.LayerNorm(vh)))
+        aux = HipSequential(nn.Linear(tower.hidden_size, vh), nn.GELU(), nn.Linear(vh, vh), nn.LayerNorm(vh))
+        aux.fp8_heavy = True     # rows = every tower token: fp8 forward GEMMs under config.fp8_projections
+        setattr(owner, f"mm_projector_aux_{aux_i}", aux)
     n_towers = len(vision_tower_aux_list)
     for g in range(n_group):
         sizes = [int(t ** 0.5) // int(query_num_list[g] ** 0.5) for t in token_lens]

@@ -299,9 +299,16 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
     def device(self):
         return self.lm_head.weight.device
 
-    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
-                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
-                image_aux_attention_masks_list=None, image_sizes=None, return_dict=None, cache_position=None):
+    def forward(self, *args, **kwargs):
+        """``config.fp8_projections`` (BASELINE configs[4]): the forward GEMMs of the SVA-side projections — aux
+        projectors, connector and in-LLM SVA layers, mm_projector, i.e. everything that goes through ``ops.linear`` —
+        run on the fp8 MFMA with row-wise e4m3 scaling; towers and decoder are untouched, the backward stays bf16."""
+        with ops.fp8_projections(bool(getattr(self.config, "fp8_projections", False))):
+            return self._forward(*args, **kwargs)
+
+    def _forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,
+                 image_aux_attention_masks_list=None, image_sizes=None, return_dict=None, cache_position=None):
         sva = _masks = _final_size = _ctx = None
         if inputs_embeds is None:  # cambrian_llama.py:315-336
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels, sva, _masks, _final_size,

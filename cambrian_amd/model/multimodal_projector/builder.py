@@ -15,7 +15,9 @@ from ... import ops
 
 
 class HipSequential(nn.Sequential):
-    """nn.Sequential of Linear / GELU / LayerNorm whose forward is executed by the C-ABI kernels."""
+    """nn.Sequential of Linear / GELU / LayerNorm whose forward is executed by the C-ABI kernels.  ``fp8_heavy`` (set on
+    the aux projectors, whose rows are all tower tokens) lets ``ops.fp8_projections`` move its GEMMs to the fp8 MFMA."""
+    fp8_heavy = False
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         shape = x.shape
@@ -28,7 +30,7 @@ class HipSequential(nn.Sequential):
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.GELU)
                 if fuse and getattr(mods[i + 1], "approximate", "none") != "none":
                     raise L.CambrianAmdError("only the exact-erf nn.GELU() of the reference is fused")
-                y = ops.linear(y, m.weight, m.bias, act=L.ACT_GELU_ERF if fuse else L.ACT_NONE)
+                y = ops.linear(y, m.weight, m.bias, act=L.ACT_GELU_ERF if fuse else L.ACT_NONE, heavy=self.fp8_heavy)
                 i += 2 if fuse else 1
             elif isinstance(m, nn.LayerNorm):
                 y = ops.layernorm(y, m.weight, m.bias, m.eps)

@@ -119,7 +119,7 @@ class VisionCrossAttentionLayer(nn.Module):
             side = s if window_major else qside * s
             n = ops.sva_norm(f, pos, holders[i], side, s, ca.k_proj_0[0].eps)
             w, b = ca.folded_kv(i)
-            kvs.append(ops.linear(n, w, b))
+            kvs.append(ops.linear(n, w, b, heavy=True))   # K|V projection of every tower token
         o = ops.sva_attention(qh, kvs, list(masks_u8), list(self.kv_size_list), B, qside, ca.num_heads, ca.head_dim,
                               window_major=window_major)
         y0 = ops.linear(o, ca.o_proj.weight, residual=x)                        # x + attn  (:319)

@@ -131,6 +131,108 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
     return out
 
 
+def k_quantize_fp8_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [rows, K] (bf16 / fp32, K-contiguous) -> (uint8 e4m3fn bytes [rows, K], fp32 dequantisation factor [rows]):
+    each row scaled so that its largest magnitude maps to 448 (cmb_quantize_fp8_rows)."""
+    L.require_gpu(x)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise L.CambrianAmdError("fp8 quantisation needs a 2-D K-contiguous tensor")
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rc = L.load().cmb_quantize_fp8_rows(L.dtype_code(x.dtype), x.data_ptr(), x.stride(0), rows, K, q.data_ptr(), K,
+                                        inv.data_ptr(), L.stream_ptr(x.device))
+    L.check(rc, f"cmb_quantize_fp8_rows({rows}x{K})")
+    return q, inv
+
+
+def k_gemm_fp8(a_q: torch.Tensor, a_inv: torch.Tensor, w_q: torch.Tensor, w_inv: torch.Tensor, *,
+               bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, colscale: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, r_map: Optional[RowMap] = None,
+               pre_out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """C[M,N] = epilogue(a_inv[m] * w_inv[n] * (A_q[M,K] . W_q[N,K]^T)) on v_mfma_f32_32x32x64_f8f6f4; operands are the
+    e4m3fn bytes / factors of k_quantize_fp8_rows; residual / pre_out are bf16; C is bf16 or fp32."""
+    L.require_gpu(a_q, a_inv, w_q, w_inv, bias, colscale, residual, pre_out)
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    if a_q.dtype != torch.uint8 or w_q.dtype != torch.uint8 or w_q.shape[1] != K or not (a_q.is_contiguous() and w_q.is_contiguous()):
+        raise L.CambrianAmdError("fp8 gemm operands must be contiguous uint8 [M,K] / [N,K]")
+    out = torch.empty((M, N), dtype=out_dtype, device=a_q.device)
+    d = GemmDesc()
+    d.dtype, d.out_dtype = L.FP8_E4M3, L.dtype_code(out_dtype)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.a_map = a_q.data_ptr(), L.identity_map(K)
+    d.B, d.ldb = w_q.data_ptr(), K
+    d.C, d.c_map = out.data_ptr(), L.identity_map(N)
+    d.bias, d.colscale = L.ptr(bias), L.ptr(colscale)
+    if residual is not None:
+        if residual.dtype != torch.bfloat16:
+            raise L.CambrianAmdError("fp8 gemm residual must be bf16")
+        d.residual, d.r_map = residual.data_ptr(), (r_map or L.identity_map(residual.stride(0)))
+    else:
+        d.residual, d.r_map = None, L.identity_map(0)
+    if pre_out is not None:
+        if pre_out.dtype != torch.bfloat16 or not pre_out.is_contiguous():
+            raise L.CambrianAmdError("fp8 gemm pre_out must be contiguous bf16")
+        d.pre_out, d.p_map = pre_out.data_ptr(), L.identity_map(N)
+    else:
+        d.pre_out, d.p_map = None, L.identity_map(0)
+    d.act, d.alpha, d.beta, d.split_k, d.tile_hint = act, 1.0, 0.0, 1, 0
+    d.workspace, d.workspace_bytes = None, 0
+    d.a_scale, d.b_scale = a_inv.data_ptr(), w_inv.data_ptr()
+    rc = L.load().cmb_gemm(C.byref(d), L.stream_ptr(a_q.device))
+    L.check(rc, f"cmb_gemm(fp8, M={M},N={N},K={K})")
+    return out
+
+
+# Forward GEMMs of ops.linear in fp8 (BASELINE configs[4]: "fp8 MFMA projection GEMMs").  The model glue switches it on
+# around the SVA-side projections when config.fp8_projections is set; towers and the decoder never see it.
+_FP8_LINEAR = False
+_FP8_WEIGHT_CACHE: dict = {}
+
+
+class fp8_projections:
+    """Context manager: ``with ops.fp8_projections(True): ...`` — ops.linear(..., heavy=True) quantises x and W row-wise
+    to e4m3fn and runs the forward GEMM on the fp8 MFMA; the backward stays bf16 (dX, dW from the saved bf16 operands)."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _FP8_LINEAR
+        self.prev, _FP8_LINEAR = _FP8_LINEAR, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _FP8_LINEAR
+        _FP8_LINEAR = self.prev
+        return False
+
+
+def _fp8_weight(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Quantised copy of a projection weight.  nn.Parameters are cached by identity and re-made when the parameter
+    changes (optimizer step => _version bump); anything else (views, weights folded on the fly) is quantised per call —
+    a pointer-keyed cache would hand a recycled allocation somebody else's bytes."""
+    w2 = weight.detach()
+    if w2.stride(1) != 1 or (w2.stride(0) * w2.element_size()) % 16 != 0 or w2.data_ptr() % 16 != 0:
+        w2 = w2.contiguous()
+    if not isinstance(weight, torch.nn.Parameter):
+        return k_quantize_fp8_rows(w2)
+    key = id(weight)
+    hit = _FP8_WEIGHT_CACHE.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != (weight._version, weight.data_ptr()):
+        import weakref
+        hit = (weakref.ref(weight, lambda _r, k=key: _FP8_WEIGHT_CACHE.pop(k, None)), (weight._version, weight.data_ptr())) \
+            + k_quantize_fp8_rows(w2)
+        _FP8_WEIGHT_CACHE[key] = hit
+    return hit[2], hit[3]
+
+
+def fp8_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (_FP8_LINEAR and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] % 128 == 0
+            and weight.shape[0] % 8 == 0 and weight.dtype in (torch.bfloat16, torch.float32))
+
+
 # bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k, tile) per GEMM launch
 GEMM_PROFILE = None
 GEMM_PROFILE_TILE = 0  # 0 = time every GEMM launch; 128 / 256 = only launches of that tile configuration
@@ -286,7 +388,7 @@ class LinearFn(torch.autograd.Function):
     (the per-image context term of proj_in, vision_sampler.py:279-292, never materialised per query)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act: int, residual, res_rep: int, colscale):
+    def forward(ctx, x, weight, bias, act: int, residual, res_rep: int, colscale, heavy: bool = False):
         dt = x.dtype
         w_c = k_cast(weight, dt)
         b_c = None if bias is None else k_cast(bias, torch.float32)
@@ -300,7 +402,13 @@ class LinearFn(torch.autograd.Function):
                 if residual.dim() != 2 or residual.shape[0] * res_rep != x.shape[0]:
                     raise L.CambrianAmdError("broadcast residual must be [M/res_rep, N]")
                 r_map = L.make_map(res_rep, 1, residual.stride(0), 0, 0)
-        y = k_gemm(x, w_c, bias=b_c, act=act, residual=residual, r_map=r_map, colscale=colscale, pre_out=pre)
+        if heavy and fp8_linear_eligible(x, weight):
+            xq, xinv = k_quantize_fp8_rows(x if x.is_contiguous() else x.contiguous())
+            wq, winv = _fp8_weight(weight)
+            y = k_gemm_fp8(xq, xinv, wq, winv, bias=b_c, act=act, residual=residual, r_map=r_map, colscale=colscale,
+                           pre_out=pre)
+        else:
+            y = k_gemm(x, w_c, bias=b_c, act=act, residual=residual, r_map=r_map, colscale=colscale, pre_out=pre)
         ctx.act = act
         ctx.has_bias = bias is not None
         ctx.res_rep = res_rep
@@ -314,7 +422,7 @@ class LinearFn(torch.autograd.Function):
         x, w_c, pre, colscale = ctx.saved_tensors
         dt = x.dtype
         dy = _as_dtype_contig(dy, dt)
-        need_x, need_w, need_b, _, need_res, _, _ = ctx.needs_input_grad
+        need_x, need_w, need_b, _, need_res = ctx.needs_input_grad[:5]
         M, K = x.shape
         N = w_c.shape[0]
         dres = None
@@ -351,14 +459,16 @@ class LinearFn(torch.autograd.Function):
             db = k_colsum(g)
             if ctx.b_dtype != torch.float32:
                 db = db.to(ctx.b_dtype)
-        return dx, dw, db, None, dres, None, None
+        return dx, dw, db, None, dres, None, None, None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE,
            residual: Optional[torch.Tensor] = None, res_rep: int = 0,
-           colscale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """2-D linear on the HIP GEMM.  x [M,K] -> [M,N]."""
-    return LinearFn.apply(x, weight, bias, act, residual, res_rep, colscale)
+           colscale: Optional[torch.Tensor] = None, heavy: bool = False) -> torch.Tensor:
+    """2-D linear on the HIP GEMM.  x [M,K] -> [M,N].  ``heavy`` marks the KV-side projections (aux projectors, SVA
+    K/V projections: M = every tower token, >85 % of the SVA-side FLOPs) — the ones ``fp8_projections`` moves to the
+    fp8 MFMA; the query-side GEMMs (M = 576 per image) stay bf16."""
+    return LinearFn.apply(x, weight, bias, act, residual, res_rep, colscale, heavy)
 
 
 # ================================================================================================

@@ -43,6 +43,9 @@ typedef enum cmb_status {
 } cmb_status;
 
 enum { CMB_BF16 = 0, CMB_F32 = 1 };
+/* 8-bit operands of cmb_gemm (OCP e4m3fn, gfx950's native fp8; BASELINE configs[4] "fp8 MFMA projection GEMMs"):
+ * A / B are uint8 [rows, K] produced by cmb_quantize_fp8_rows, C / residual / pre_out are bf16 (or fp32 C). */
+enum { CMB_FP8_E4M3 = 3 };
 enum { CMB_ACT_NONE = 0, CMB_ACT_GELU_ERF = 1, CMB_ACT_GELU_TANH = 2, CMB_ACT_QUICK_GELU = 3,
        CMB_ACT_SILU = 4 };
 
@@ -66,6 +69,8 @@ int cmb_abi_version(void);
  * epilogue order:  v = alpha*acc + bias[n];  pre_out = v;  v = act(v);  v *= colscale[n];
  *                  v += residual[m,n];  v += beta*C_old[m,n] (fp32 C only);  C = v
  * requirements: K % (128 / sizeof(elem)) == 0; N % 8 == 0; 16-byte aligned rows.
+ * dtype CMB_FP8_E4M3: v_mfma_f32_32x32x64_f8f6f4 (K = 64 per instruction, twice the bf16 MFMA rate), 128x128 tile,
+ *   no split-K; see a_scale / b_scale.
  * two tile configurations: 128x128 / 4 waves, and for bf16 256x256 / 8 waves with the
  *   8-phase LDS-DMA schedule; `tile_hint` = 0 lets the library pick by grid fill.
  * split_k > 1: fp32 partial slabs go to `workspace` (split_k*M*N*4 bytes) and are reduced by a
@@ -88,9 +93,18 @@ typedef struct cmb_gemm_desc {
   void* workspace; int64_t workspace_bytes;
   int32_t tile_hint;       /* 0 = choose by grid-fill cost model; 128 / 256 = force that block tile (bf16 only);
                               2560 / 2561 = 256 tile with schedule 0 (8-phase ping-pong, default) / 1 (in-wave pipeline) */
+  const float* a_scale;    /* CMB_FP8_E4M3 only: [M] fp32 dequantisation factor of each A row (or NULL = 1) */
+  const float* b_scale;    /* CMB_FP8_E4M3 only: [N] fp32 dequantisation factor of each B row (or NULL = 1);
+                              the accumulator is multiplied by a_scale[m] * b_scale[n] before alpha / bias */
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);
+/* Row-wise fp8 quantisation for cmb_gemm(CMB_FP8_E4M3): for every row r of x [rows, K] (dtype CMB_BF16 | CMB_F32, row
+ * stride ldx elements):  amax = max|x[r,:]|;  s = 448 / amax (1 if amax == 0);
+ * q[r,k] = e4m3fn_rne(clamp(x[r,k] * s, -448, 448));  inv_scale[r] = amax / 448 (1 if amax == 0).
+ * One pass over x (a row lives in registers between the reduction and the cast).  K % 16 == 0, ldq % 16 == 0. */
+int cmb_quantize_fp8_rows(int dtype, const void* x, int64_t ldx, int64_t rows, int64_t K, void* q, int64_t ldq,
+                          float* inv_scale, void* stream);
 /* block tile (128 or 256) cmb_gemm would run for this problem — lets the caller label profiles / rooflines per
  * kernel configuration.  dtype CMB_F32 always answers 128. */
 int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint);

@@ -239,6 +239,22 @@ def test_config34_hook_geometry_and_phi3_sva(dev, monkeypatch, lm, nkv, window):
     _compare(dev, dt, model, cfg, towers, batch, 1e-3, 5e-3, min_checked=50)
 
 
+def test_config4_fp8_projection_gemms(dev, monkeypatch):
+    """BASELINE configs[4]: ``config.fp8_projections`` — forward GEMMs of the SVA-side projections in fp8 (row-wise e4m3fn,
+    v_mfma_f32_32x32x64_f8f6f4), bf16 everywhere else.  Tolerance vs the fp32 oracle: logits 8e-2 rel (bf16 mode: 5e-2),
+    trainable-parameter gradients 2.5e-1 rel (bf16 mode: 1.5e-1)."""
+    from cambrian_amd import ops
+    from cambrian_amd.train.data_layout import synthetic_batch
+    dt = torch.bfloat16
+    model, cfg, towers = _build(dev, dt, monkeypatch)
+    cfg.fp8_projections = True
+    batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
+                            image_res=[56, 64], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
+    n0 = len(ops._FP8_WEIGHT_CACHE)
+    _compare(dev, dt, model, cfg, towers, batch, 8e-2, 2.5e-1, min_checked=50)
+    assert len(ops._FP8_WEIGHT_CACHE) > n0 and not ops._FP8_LINEAR
+
+
 def test_text_only_early_out(dev, monkeypatch):
     """cambrian_arch.py:346-347: no images -> inputs returned untouched, plain LM forward."""
     model, cfg, towers = _build(dev, torch.float32, monkeypatch)
