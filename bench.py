@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
                     "config 4's partitioning) instead of all-reduce + replicated AdamW")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--fp8-projections", action="store_true",
+                    help="BASELINE configs[4] mode: forward GEMMs of the KV-side SVA projections in fp8 (marks the line: "
+                         "not the bf16 headline configuration)")
     ap.add_argument("--input-pipeline", action="store_true",
                     help="feed decoded uint8 images through the GPU input pipeline (SURVEY.md §8f N3: pinned H2D + "
                          "cmb_image_preprocess on a side stream, one batch ahead) instead of resident pixel tensors")
@@ -167,6 +170,7 @@ def main():
     tuned = args.tuned_llm_gemms and load_tuned_llm_gemms()
 
     model, cfg = build_model(dev, args.llm_layers)
+    cfg.fp8_projections = bool(args.fp8_projections)
     params = [p for p in model.parameters() if p.requires_grad]
     if args.zero2:
         from cambrian_amd.train.zero import Zero2AdamW
@@ -247,6 +251,9 @@ def main():
                        "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
                        "llm_gemm_solutions": "pre-tuned TunableOp table" if tuned else "PyTorch default heuristic"},
         }
+        if args.fp8_projections:
+            line["dtype"] = "bf16 + fp8 (e4m3, row-wise scales) forward GEMMs of the KV-side SVA projections"
+            line["config"]["NOT_HEADLINE"] = "reduced-precision mode of BASELINE configs[4]; the headline line is the bf16 run"
         if args.llm_layers is not None:
             line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"
         if prof:
