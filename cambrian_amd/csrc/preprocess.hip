@@ -7,26 +7,33 @@
 // the uint8 intermediate adds 2 * 3*S*R.  Per-thread arithmetic lives in preprocess_core.h (shared with the CPU
 // simulation in tests/csrc/preprocess_sim.cpp).
 //
-// pass H  grid (ceil(max S*R / 256), jobs): thread = one (y, xo); lanes of a wave walk neighbouring xo, so the
+// Jobs differ in size by two orders of magnitude (a 224x224 icon into a 336 tower vs a 1920x1080 photo into the 1024
+// tower), so a (max blocks, jobs) grid would be mostly empty blocks: each pass is ONE 1-D grid whose blocks are dealt
+// to jobs through a prefix table passed by value in the kernel arguments (scalar binary search, no device memory).
+// pass H  thread = one (y, xo); lanes of a wave walk neighbouring xo, so the
 //         source bytes of a tap are a short contiguous run (upscale) or a strided run that stays in L1 across
 //         taps (downscale); coefficients are tap-major [ksize, R] -> coalesced.  Plane writes are byte-coalesced.
-// pass V  grid (ceil(max R*pitch/4 / 256), jobs): thread = 4 neighbouring columns of one output row: one 32-bit
+// pass V  thread = 4 neighbouring columns of one output row: one 32-bit
 //         load per plane and tap (coalesced across the wave), 12 accumulators, table lookup, 4-wide store.
 #include "common.h"
 #include "preprocess_core.h"
 
 namespace {
 
-constexpr int PP_THREADS = 256;
+constexpr int PP_THREADS = CMB_PP_THREADS;
+constexpr int PP_MAX_JOBS = CMB_PP_MAX_JOBS;
+typedef cmb_block_starts BlockStarts;
+#define job_of_block cmb_job_of_block
 
 __global__ __launch_bounds__(PP_THREADS) void image_resample_h_kernel(const cmb_image_job* __restrict__ jobs,
                                                                       const uint8_t* __restrict__ src,
                                                                       const int32_t* __restrict__ bounds,
                                                                       const int32_t* __restrict__ coefs,
-                                                                      uint8_t* __restrict__ tmp) {
-  const cmb_image_job J = jobs[blockIdx.y];
-  if (J.ksize == 0) return;
-  const int64_t g = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x;
+                                                                      uint8_t* __restrict__ tmp,
+                                                                      const BlockStarts starts) {
+  const int j = job_of_block(starts, (int)blockIdx.x);
+  const cmb_image_job J = jobs[j];
+  const int64_t g = (int64_t)((int)blockIdx.x - starts.start[j]) * PP_THREADS + threadIdx.x;
   if (g >= (int64_t)J.side * J.out_side) return;
   const int y = (int)(g / J.out_side), xo = (int)(g - (int64_t)y * J.out_side);
   cmb_resample_h(src, bounds, coefs, tmp, J, y, xo);
@@ -44,10 +51,12 @@ __global__ __launch_bounds__(PP_THREADS) void image_resample_v_kernel(const cmb_
                                                                       const int32_t* __restrict__ coefs,
                                                                       const float* __restrict__ lut,
                                                                       const uint8_t* __restrict__ tmp,
-                                                                      T* __restrict__ dst) {
-  const cmb_image_job J = jobs[blockIdx.y];
+                                                                      T* __restrict__ dst,
+                                                                      const BlockStarts starts) {
+  const int j = job_of_block(starts, (int)blockIdx.x);
+  const cmb_image_job J = jobs[j];
   const int R = J.out_side, p4 = cmb_tmp_pitch(R) >> 2;
-  const int64_t g = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x;
+  const int64_t g = (int64_t)((int)blockIdx.x - starts.start[j]) * PP_THREADS + threadIdx.x;
   if (g >= (int64_t)R * p4) return;
   const int yo = (int)(g / p4), x4 = (int)(g - (int64_t)yo * p4);
   int levels[3][4];
@@ -85,7 +94,6 @@ extern "C" int cmb_image_preprocess(const cmb_image_job* jobs_dev, const cmb_ima
   if (n_jobs == 0) return CMB_OK;
   if (!jobs_dev || !jobs_host || n_jobs < 0 || !src || !lut || !dst) return CMB_ERR_BAD_ARG;
   if (out_dtype != CMB_BF16 && out_dtype != CMB_F32 && out_dtype != CMB_F16) return CMB_ERR_BAD_ARG;
-  int64_t max_h = 0, max_v = 0;
   for (int i = 0; i < n_jobs; ++i) {
     const cmb_image_job& J = jobs_host[i];
     if (J.w <= 0 || J.h <= 0 || J.out_side <= 0 || J.side != (J.w > J.h ? J.w : J.h)) return CMB_ERR_SHAPE;
@@ -95,28 +103,31 @@ extern "C" int cmb_image_preprocess(const cmb_image_job* jobs_dev, const cmb_ima
     } else {
       if (!bounds || !coefs || !tmp) return CMB_ERR_BAD_ARG;
       if (J.tmp_off & 3) return CMB_ERR_ALIGNMENT;
-      const int64_t nh = (int64_t)J.side * J.out_side;
-      if (nh > max_h) max_h = nh;
     }
-    const int64_t nv = (int64_t)J.out_side * (cmb_tmp_pitch(J.out_side) >> 2);
-    if (nv > max_v) max_v = nv;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (max_h > 0) {
-    dim3 grid((unsigned)((max_h + PP_THREADS - 1) / PP_THREADS), (unsigned)n_jobs);
-    hipLaunchKernelGGL(image_resample_h_kernel, grid, dim3(PP_THREADS), 0, s, jobs_dev, src, bounds, coefs, tmp);
+  for (int j0 = 0; j0 < n_jobs; j0 += PP_MAX_JOBS) {
+    const int nj = n_jobs - j0 < PP_MAX_JOBS ? n_jobs - j0 : PP_MAX_JOBS;
+    BlockStarts hs, vs;
+    int64_t hb, vb;
+    if (!cmb_block_tables(jobs_host + j0, nj, &hs, &vs, &hb, &vb)) return CMB_ERR_SHAPE;
+    const cmb_image_job* jd = jobs_dev + j0;
+    if (hb > 0) {
+      hipLaunchKernelGGL(image_resample_h_kernel, dim3((unsigned)hb), dim3(PP_THREADS), 0, s, jd, src, bounds, coefs, tmp,
+                         hs);
+      CMB_CHECK_LAUNCH();
+    }
+    const dim3 grid((unsigned)vb);
+    if (out_dtype == CMB_F32)
+      hipLaunchKernelGGL(image_resample_v_kernel<float>, grid, dim3(PP_THREADS), 0, s, jd, src, bounds, coefs, lut, tmp,
+                         (float*)dst, vs);
+    else if (out_dtype == CMB_BF16)
+      hipLaunchKernelGGL(image_resample_v_kernel<bf16_t>, grid, dim3(PP_THREADS), 0, s, jd, src, bounds, coefs, lut, tmp,
+                         (bf16_t*)dst, vs);
+    else
+      hipLaunchKernelGGL(image_resample_v_kernel<_Float16>, grid, dim3(PP_THREADS), 0, s, jd, src, bounds, coefs, lut,
+                         tmp, (_Float16*)dst, vs);
     CMB_CHECK_LAUNCH();
   }
-  dim3 grid((unsigned)((max_v + PP_THREADS - 1) / PP_THREADS), (unsigned)n_jobs);
-  if (out_dtype == CMB_F32)
-    hipLaunchKernelGGL(image_resample_v_kernel<float>, grid, dim3(PP_THREADS), 0, s, jobs_dev, src, bounds, coefs, lut,
-                       tmp, (float*)dst);
-  else if (out_dtype == CMB_BF16)
-    hipLaunchKernelGGL(image_resample_v_kernel<bf16_t>, grid, dim3(PP_THREADS), 0, s, jobs_dev, src, bounds, coefs,
-                       lut, tmp, (bf16_t*)dst);
-  else
-    hipLaunchKernelGGL(image_resample_v_kernel<_Float16>, grid, dim3(PP_THREADS), 0, s, jobs_dev, src, bounds, coefs,
-                       lut, tmp, (_Float16*)dst);
-  CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

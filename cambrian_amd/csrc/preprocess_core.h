@@ -48,11 +48,23 @@ CMB_PHD void cmb_resample_h(const uint8_t* src, const int32_t* bounds, const int
   if ((unsigned)sy < (unsigned)J.h) {
     const uint8_t* row = src + J.src_off + (int64_t)sy * J.w * 3;
     const int bg0 = J.background & 255, bg1 = (J.background >> 8) & 255, bg2 = (J.background >> 16) & 255;
+    // one unaligned 32-bit load per pixel (r, g, b + the next pixel's r); only the very last pixel of the image has
+    // no byte behind it and is read bytewise
+    const bool last_row = sy == J.h - 1;
     for (int j = 0; j < count; ++j) {
       const int32_t kj = k[(int64_t)j * R];
       const int sx = first + j - J.off_x;
       int p0 = bg0, p1 = bg1, p2 = bg2;
-      if ((unsigned)sx < (unsigned)J.w) { p0 = row[sx * 3]; p1 = row[sx * 3 + 1]; p2 = row[sx * 3 + 2]; }
+      if ((unsigned)sx < (unsigned)J.w) {
+        const uint8_t* px = row + sx * 3;
+        if (last_row && sx == J.w - 1) {
+          p0 = px[0]; p1 = px[1]; p2 = px[2];
+        } else {
+          uint32_t v;
+          __builtin_memcpy(&v, px, 4);
+          p0 = v & 255; p1 = (v >> 8) & 255; p2 = (v >> 16) & 255;
+        }
+      }
       a0 += p0 * kj; a1 += p1 * kj; a2 += p2 * kj;
     }
   } else {  // a bar row: a constant colour through the same fixed-point taps
@@ -99,6 +111,50 @@ CMB_PHD void cmb_copy_levels(const uint8_t* src, const cmb_image_job& J, int yo,
     const uint32_t p = x < J.out_side ? cmb_virtual_pixel(src, J, yo, x) : 0u;
     levels[0][i] = p & 255; levels[1][i] = (p >> 8) & 255; levels[2][i] = (p >> 16) & 255;
   }
+}
+
+// ---- block -> job mapping ---------------------------------------------------------------------------------------
+// Each pass is one 1-D grid; blocks are dealt to jobs through a prefix table passed by value in the kernel arguments.
+#define CMB_PP_THREADS 256
+#define CMB_PP_MAX_JOBS 256   // jobs per launch (larger tables are cut into several launches)
+
+struct cmb_block_starts {
+  int32_t n;
+  int32_t start[CMB_PP_MAX_JOBS + 1];  // start[j] = first block of job j; start[n] = grid size
+};
+
+// largest j with start[j] <= b (b < start[n]; empty jobs have start[j] == start[j+1]); uniform over the block
+CMB_PHD int cmb_job_of_block(const cmb_block_starts& t, int b) {
+  int lo = 0, hi = t.n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.start[mid] <= b) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+CMB_PHD int64_t cmb_h_blocks(const cmb_image_job& J) {
+  return J.ksize == 0 ? 0 : ((int64_t)J.side * J.out_side + CMB_PP_THREADS - 1) / CMB_PP_THREADS;
+}
+CMB_PHD int64_t cmb_v_blocks(const cmb_image_job& J) {
+  return ((int64_t)J.out_side * (cmb_tmp_pitch(J.out_side) >> 2) + CMB_PP_THREADS - 1) / CMB_PP_THREADS;
+}
+
+// host: prefix tables of both passes for nj <= CMB_PP_MAX_JOBS jobs; false if a grid would not fit in 31 bits
+static inline bool cmb_block_tables(const cmb_image_job* jobs, int nj, cmb_block_starts* hs, cmb_block_starts* vs,
+                                    int64_t* h_total, int64_t* v_total) {
+  int64_t hb = 0, vb = 0;
+  hs->n = vs->n = nj;
+  for (int i = 0; i < nj; ++i) {
+    hs->start[i] = (int32_t)hb;
+    vs->start[i] = (int32_t)vb;
+    hb += cmb_h_blocks(jobs[i]);
+    vb += cmb_v_blocks(jobs[i]);
+    if (hb > 0x7fffffff || vb > 0x7fffffff) return false;
+  }
+  for (int i = nj; i <= CMB_PP_MAX_JOBS; ++i) { hs->start[i] = (int32_t)hb; vs->start[i] = (int32_t)vb; }
+  *h_total = hb; *v_total = vb;
+  return true;
 }
 
 // ---- host: coefficient rows (precompute_coeffs + normalize_coeffs_8bpc) ------------------------------------
