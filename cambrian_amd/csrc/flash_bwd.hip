@@ -34,6 +34,7 @@ struct FlashParams {
   int64_t q_sb, q_ss, q_sh;     // strides of q / o / do / dq (elements)
   int64_t kv_sb, kv_ss, kv_sh;  // strides of k / v / dk / dv
   int B, S, H, HKV;
+  int kv_len;   // non-causal kernels: keys >= kv_len are padding (masked); S is kv_len rounded up to 128
   float scale;
 };
 
@@ -98,6 +99,7 @@ __device__ __forceinline__ void stage_tile64(const bf16_t* src, int64_t rs, int 
 // accumulator -> operand without shuffles and V^T fragments from the transposed V image.  K/V heads are shared by the
 // query heads of a group without being expanded.  Writes O (bf16) and lse = log sum_j exp(scale q.k_j) (fp32).
 // ------------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
 __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse_out) {
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
@@ -122,13 +124,13 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  const int nt = (qb * 128 + 128) / 64;
+  const int nt = CAUSAL ? (qb * 128 + 128) / 64 : (p.kv_len + 63) / 64;
   for (int t = 0; t < nt; ++t) {
     __syncthreads();
     stage_tile64<true, false>(kbase, p.kv_ss, t * 64, p.S, sK, nullptr, tid);
     stage_tile64<false, true>(vbase, p.kv_ss, t * 64, p.S, nullptr, sVT, tid);
     __syncthreads();
-    if (t * 64 > q0 + 31) continue;
+    if (CAUSAL && t * 64 > q0 + 31) continue;
     f32x16_t s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float v = (key <= qi) ? s[kt][r] * c2 : -INFINITY;
+        const float v = (CAUSAL ? key <= qi : key < p.kv_len) ? s[kt][r] * c2 : -INFINITY;
         s[kt][r] = v;
         mx = fmaxf(mx, v);
       }
@@ -203,7 +205,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
 // ------------------------------------------------------------------------------------------------------------------
 // dQ: grid (S/128, H, B), 256 threads.  lane = (query j = lane & 31 of the wave's 32, half g = lane >> 5).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) flash_dq_kernel(const FlashParams p) {
+template <bool CAUSAL>
+__global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const FlashParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
   __shared__ __attribute__((aligned(16))) bf16_t sV[64 * LDR];
   __shared__ __attribute__((aligned(16))) bf16_t sKT[HD * LDT];
@@ -234,13 +237,14 @@ __global__ void __launch_bounds__(256, 2) flash_dq_kernel(const FlashParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
-  const int nt = (qb * 128 + 128) / 64;  // key tiles up to and including the diagonal ones
+  const int nt = CAUSAL ? (qb * 128 + 128) / 64   // key tiles up to and including the diagonal ones
+                        : (p.kv_len + 63) / 64;   // every tile that holds a real key
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // previous tile fully consumed
     stage_tile64<true, true>(kbase, p.kv_ss, t * 64, p.S, sK, sKT, tid);
     stage_tile64<true, false>(vbase, p.kv_ss, t * 64, p.S, sV, nullptr, tid);
     __syncthreads();
-    if (t * 64 > q0 + 31) continue;  // whole tile above this wave's diagonal (block-uniform barriers stay matched)
+    if (CAUSAL && t * 64 > q0 + 31) continue;  // whole tile above this wave's diagonal (block-uniform barriers stay matched)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16_t s, dp;
@@ -256,7 +260,7 @@ __global__ void __launch_bounds__(256, 2) flash_dq_kernel(const FlashParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float pr = (key <= qi) ? __builtin_amdgcn_exp2f(s[r] * c2 - lse2) : 0.f;
+        const float pr = (CAUSAL ? key <= qi : key < p.kv_len) ? __builtin_amdgcn_exp2f(s[r] * c2 - lse2) : 0.f;
         s[r] = pr * (dp[r] - dq_d);  // dS^T (the 1/sqrt(d) factor is applied once at the end)
       }
 #pragma unroll
@@ -295,6 +299,7 @@ __global__ void __launch_bounds__(256, 2) flash_dq_kernel(const FlashParams p) {
 // workgroup by a register prefetch (see the loop).  (A double-buffered-LDS variant with one barrier per tile measured
 // slower: 506 registers, values shuffled through the accumulator file.)
 // ------------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
 __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);   // [64][LDR]
@@ -325,7 +330,7 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { adk[d][r] = 0.f; adv[d][r] = 0.f; }
 
-  const int qt0 = (kb * 128) / 64, nqt = p.S / 64;
+  const int qt0 = CAUSAL ? (kb * 128) / 64 : 0, nqt = p.S / 64;
   // Register prefetch: the global loads of the NEXT (head, query tile) are issued right after the barrier that
   // publishes the current tile and stay in flight during its 64 MFMAs; they are written to LDS after the next barrier.
   // Thread <-> (row pair rp, d group dg) x 2 passes, as in stage_tile64.
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
         const int nh = last_q ? h + 1 : h, nq = last_q ? qt0 : qt + 1;
         if (!(last_q && hq + 1 == group)) DKDV_LOAD(nh, nq);
       }
-      if (qt * 64 + 63 < k0) continue;  // every query of the tile precedes this wave's keys
+      if (CAUSAL && qt * 64 + 63 < k0) continue;  // every query of the tile precedes this wave's keys
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs) {
         f32x16_t s, dp;
@@ -403,7 +408,7 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * r4 + e;
             const int qidx = qt * 64 + qrow + e;
-            const float pv = (ki <= qidx) ? __builtin_amdgcn_exp2f(s[r] * c2 - l4[e]) : 0.f;
+            const float pv = (CAUSAL ? ki <= qidx : ki < p.kv_len) ? __builtin_amdgcn_exp2f(s[r] * c2 - l4[e]) : 0.f;
             pr[r] = pv;
             s[r] = pv * (dp[r] - d4[e]);  // dS
           }
@@ -458,9 +463,11 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
 extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                                   const float* lse, int64_t B, int64_t S, int32_t H, int32_t HKV, int32_t hd,
                                   int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
-                                  float scale, float* dvec, void* dq, void* dk, void* dv, void* stream) {
+                                  float scale, int32_t causal, int64_t kv_len, float* dvec, void* dq, void* dk, void* dv,
+                                  void* stream) {
   if (!q || !k || !v || !o || !dout || !lse || !dvec || !dq || !dk || !dv) return CMB_ERR_BAD_ARG;
   if (hd != HD || S <= 0 || (S % 128) != 0 || H <= 0 || HKV <= 0 || (H % HKV) != 0 || B < 0) return CMB_ERR_SHAPE;
+  if (!causal && (kv_len <= 0 || kv_len > S)) return CMB_ERR_SHAPE;
   if (B == 0) return CMB_OK;
   if ((q_ss % 8) || (q_sh % 8) || (q_sb % 8) || (kv_ss % 8) || (kv_sh % 8) || (kv_sb % 8)) return CMB_ERR_ALIGNMENT;
   FlashParams p;
@@ -468,41 +475,54 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   p.dout = (const bf16_t*)dout; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
   p.lse = lse; p.dvec = dvec;
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
-  p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale;
+  p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
   hipStream_t s = (hipStream_t)stream;
   {
     int64_t rows = B * S * H, blocks = (rows + 3) / 4;
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(flash_dvec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   }
-  hipLaunchKernelGGL(flash_dq_kernel, dim3((unsigned)(S / 128), (unsigned)H, (unsigned)B), dim3(256), 0, s, p);
+  const dim3 gq((unsigned)(S / 128), (unsigned)H, (unsigned)B), gk((unsigned)(S / 128), (unsigned)HKV, (unsigned)B);
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return CMB_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(flash_dkdv_kernel, dim3((unsigned)(S / 128), (unsigned)HKV, (unsigned)B), dim3(256), smem, s, p);
+  if (causal) {
+    hipLaunchKernelGGL(flash_dq_kernel<true>, gq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(flash_dkdv_kernel<true>, gk, dim3(256), smem, s, p);
+  } else {
+    hipLaunchKernelGGL(flash_dq_kernel<false>, gq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(flash_dkdv_kernel<false>, gk, dim3(256), smem, s, p);
+  }
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }
 
 extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t B, int64_t S, int32_t H, int32_t HKV,
                                   int32_t hd, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss,
-                                  int64_t kv_sh, float scale, void* out, float* lse, void* stream) {
+                                  int64_t kv_sh, float scale, int32_t causal, int64_t kv_len, void* out, float* lse,
+                                  void* stream) {
   if (!q || !k || !v || !out || !lse) return CMB_ERR_BAD_ARG;
   if (hd != HD || S <= 0 || (S % 128) != 0 || H <= 0 || HKV <= 0 || (H % HKV) != 0 || B < 0) return CMB_ERR_SHAPE;
+  if (!causal && (kv_len <= 0 || kv_len > S)) return CMB_ERR_SHAPE;
   if (B == 0) return CMB_OK;
   if ((q_ss % 8) || (q_sh % 8) || (q_sb % 8) || (kv_ss % 8) || (kv_sh % 8) || (kv_sb % 8)) return CMB_ERR_ALIGNMENT;
   FlashParams p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = nullptr; p.dout = nullptr;
   p.dq = p.dk = p.dv = nullptr; p.lse = nullptr; p.dvec = nullptr;
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
-  p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale;
-  hipLaunchKernelGGL(flash_fwd_kernel, dim3((unsigned)(S / 128), (unsigned)H, (unsigned)B), dim3(256), 0,
-                     (hipStream_t)stream, p, (bf16_t*)out, lse);
+  p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
+  const dim3 grid((unsigned)(S / 128), (unsigned)H, (unsigned)B);
+  if (causal)
+    hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
+  else
+    hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

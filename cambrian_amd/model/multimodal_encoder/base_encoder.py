@@ -106,9 +106,6 @@ class BaseVisionTower(nn.Module):
         self.unfreeze_mm_vision_tower = getattr(args, "unfreeze_mm_vision_tower", False)
         self.delay_load = delay_load
         self._interp_size = None
-        if self.unfreeze_mm_vision_tower:
-            raise NotImplementedError("unfrozen vision towers need the tower backward kernels "
-                                      "(SURVEY.md §8f N4); the reference default is frozen")
 
     # -- subclasses ------------------------------------------------------------------------------
     def load_model(self, device_map=None):
@@ -123,6 +120,29 @@ class BaseVisionTower(nn.Module):
         return self._forward(images)
 
     # -- helpers ---------------------------------------------------------------------------------
+    def _make_vit(self, cfg, canon, dtype, pos_fn=None):
+        """Frozen: packed buffers + raw kernels, no graph (vit.py).  ``unfreeze_mm_vision_tower``: fp32 master
+        parameters + autograd operators (vit_train.py)."""
+        if self.unfreeze_mm_vision_tower:
+            from .vit_train import TrainableViT
+            return TrainableViT(cfg, canon, self._target_device(), dtype, pos_fn=pos_fn)
+        from .vit import ViTTrunk
+        if pos_fn is not None:
+            canon = dict(canon)
+            canon["pos"] = pos_fn(canon["pos"])
+        return ViTTrunk(cfg, dtype).load_canonical(canon, self._target_device())
+
+    def _resample(self, feats, target):
+        """Token-grid resize of the wrappers; differentiable when the tower trains."""
+        if self.unfreeze_mm_vision_tower:
+            from .vit_train import resample_tokens_autograd
+            return resample_tokens_autograd(feats, target)
+        from .vit import resample_tokens
+        return resample_tokens(feats, target, force_copy=True)
+
+    def _grad_mode(self):
+        return torch.set_grad_enabled(bool(self.unfreeze_mm_vision_tower) and torch.is_grad_enabled())
+
     @staticmethod
     def _seed_for(name: str) -> int:
         return int.from_bytes(name.encode()[:8].ljust(8, b"\0"), "little") % (2 ** 31)
@@ -145,6 +165,8 @@ class BaseVisionTower(nn.Module):
         if vt is not None:
             for b in vt.buffers():
                 return b.device
+            for q in vt.parameters():     # trainable trunk: fp32 master parameters instead of packed buffers
+                return q.device
         return torch.device("cpu")
 
     @property

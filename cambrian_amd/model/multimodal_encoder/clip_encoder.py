@@ -76,7 +76,7 @@ class ClipVisionTower(BaseVisionTower):
         else:
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
             canon = ViTTrunk.random_canonical(cfg, gen)
-        self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(canon, self._target_device())
+        self.vision_tower = self._make_vit(cfg, canon, dtype)
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, flavour="hf"), height=self._image_size,
                                                 width=self._image_size)
         self.is_loaded = True
@@ -89,10 +89,10 @@ class ClipVisionTower(BaseVisionTower):
     def interpolate(self, image_features):
         """clip_encoder.py:70-96 (also produces the contiguous [B,T,C] copy of the CLS-stripped view)."""
         target = self._interp_size if self._interp_size is not None else image_features.shape[1]
-        return resample_tokens(image_features, target, force_copy=True)
+        return self._resample(image_features, target)
 
     def _forward(self, images):
-        with torch.no_grad():  # frozen: clip_encoder.py:103
+        with self._grad_mode():  # clip_encoder.py:103: torch.set_grad_enabled(self.unfreeze_mm_vision_tower)
             feats = self.vision_tower(images.to(device=self.device))
             feats = self.interpolate(self._feature_select(feats))
             return feats.to(images.dtype) if images.dtype in (torch.float32, torch.bfloat16) else feats

@@ -97,8 +97,8 @@ class DinoVisionTower(BaseVisionTower):
         else:
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
             canon = ViTTrunk.random_canonical(native, gen)
-        canon["pos"] = interpolate_pos_encoding(canon["pos"], run.grid)  # 37x37 -> e.g. 27x27 at 378 px
-        self.vision_tower = ViTTrunk(run, dtype).load_canonical(canon, self._target_device())
+        # 37x37 -> e.g. 27x27 at 378 px: once at load when frozen, inside every forward (differentiably) when training
+        self.vision_tower = self._make_vit(run, canon, dtype, pos_fn=lambda pos: interpolate_pos_encoding(pos, run.grid))
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, IMAGENET_MEAN, IMAGENET_STD, flavour="hf"),
                                                 height=self._image_size, width=self._image_size,
                                                 image_mean=IMAGENET_MEAN)
@@ -116,10 +116,10 @@ class DinoVisionTower(BaseVisionTower):
     def interpolate(self, image_features):
         """dino_encoder.py:128-154."""
         target = self._interp_size if self._interp_size is not None else image_features.shape[1]
-        return resample_tokens(image_features, target, force_copy=True)
+        return self._resample(image_features, target)
 
     def _forward(self, images):
-        with torch.no_grad():
+        with self._grad_mode():  # dino_encoder.py:158
             feats = self.interpolate(self.feature_select(self.vision_tower(images.to(device=self.device))))
             return feats.to(images.dtype) if images.dtype in (torch.float32, torch.bfloat16) else feats
 

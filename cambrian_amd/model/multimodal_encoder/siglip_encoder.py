@@ -89,12 +89,12 @@ class SiglipVisionTower(ClipVisionTower):
         else:
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
             canon = ViTTrunk.random_canonical(cfg, gen)
-        self.vision_tower = ViTTrunk(cfg, dtype).load_canonical(canon, self._target_device())
+        self.vision_tower = self._make_vit(cfg, canon, dtype)
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, [0.5] * 3, [0.5] * 3),
                                                 height=self._image_size, width=self._image_size, image_mean=[0.5] * 3)
         self.is_loaded = True
 
     def _forward(self, images, interpolate_token=576):
-        with torch.no_grad():
+        with self._grad_mode():  # siglip_encoder.py:96
             feats = self.interpolate(self.vision_tower(images.to(device=self.device)))
             return feats.to(images.dtype) if images.dtype in (torch.float32, torch.bfloat16) else feats

@@ -16,6 +16,7 @@ import math
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+import torch.nn.functional as F
 
 from . import lib as L
 from .lib import RowMap, GemmDesc, SvaDesc
@@ -1022,29 +1023,35 @@ def _token_major(t: torch.Tensor) -> torch.Tensor:
 
 
 class CausalAttnFn(torch.autograd.Function):
-    """Causal GQA attention, head_dim 128, on flash_bwd.hip: forward kernel (online softmax, writes the log-sum-exp),
+    """GQA attention, head_dim 128, on flash_bwd.hip: forward kernel (online softmax, writes the log-sum-exp),
     backward = dQ kernel + dK/dV kernel (no atomics).  K/V are read un-expanded (grouped heads): no
-    repeat_interleave copies of K and V per layer as F.scaled_dot_product_attention(enable_gqa=True) makes."""
+    repeat_interleave copies of K and V per layer as F.scaled_dot_product_attention(enable_gqa=True) makes.
+    ``kv_len`` None: causal (the decoder).  ``kv_len`` = n: bidirectional over keys [0, n), rows [n, S) are padding
+    (trainable vision towers, see ``vit_attention``)."""
 
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, scale=None, kv_len=None):
         L.require_gpu(q, k, v)
         B, H, S, D = q.shape
         HKV = k.shape[1]
+        scale = 1.0 / math.sqrt(D) if scale is None else float(scale)
+        causal, n = (1, S) if kv_len is None else (0, int(kv_len))
         q, k, v = _token_major(q), _token_major(k), _token_major(v)
         out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
         rc = L.load().cmb_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, S, H, HKV, D, S * H * D, H * D, D,
-                                         S * HKV * D, HKV * D, D, 1.0 / math.sqrt(D), out.data_ptr(), lse.data_ptr(),
+                                         S * HKV * D, HKV * D, D, scale, causal, n, out.data_ptr(), lse.data_ptr(),
                                          L.stream_ptr(q.device))
         L.check(rc, "cmb_flash_attn_fwd")
         out = out.transpose(1, 2)  # [B,H,S,D] view of token-major storage: the o_proj input needs no copy
         ctx.save_for_backward(q, k, v, out, lse)
+        ctx.cfg = (scale, causal, n)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
+        scale, causal, n = ctx.cfg
         B, H, S, D = q.shape
         HKV = k.shape[1]
         q, out, dout = _token_major(q), _token_major(out), _token_major(dout)
@@ -1056,10 +1063,24 @@ class CausalAttnFn(torch.autograd.Function):
         lse = lse.contiguous()
         rc = L.load().cmb_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                          lse.data_ptr(), B, S, H, HKV, D, S * H * D, H * D, D, S * HKV * D, HKV * D, D,
-                                         1.0 / math.sqrt(D), dvec.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                         scale, causal, n, dvec.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                          L.stream_ptr(q.device))
         L.check(rc, "cmb_flash_attn_bwd")
-        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)
+        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None, None
+
+
+def vit_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """Bidirectional self-attention WITH a backward, for towers that train: q, k, v [B,H,N,hd] bf16
+    with any N and hd <= 128.  Runs on the decoder's flash kernels: tokens zero-padded to a multiple of 128 and masked
+    through ``kv_len``, head_dim zero-padded to 128 (zero columns change neither q.k nor the first hd output columns);
+    the padding and the final slice are ordinary autograd ops, so padded rows receive zero gradients."""
+    B, H, N, hd = q.shape
+    if hd > 128 or q.dtype != torch.bfloat16:
+        raise L.CambrianAmdError("vit_attention: bf16 and head_dim <= 128 only")
+    S = (N + 127) // 128 * 128
+    pad = (0, 128 - hd, 0, S - N)
+    qp, kp, vp = (F.pad(t, pad) for t in (q, k, v))
+    return CausalAttnFn.apply(qp, kp, vp, scale, N)[:, :, :N, :hd]
 
 
 def causal_attention_supported(q: torch.Tensor, k: torch.Tensor) -> bool:

@@ -304,14 +304,18 @@ int cmb_qkv_rope(int dtype, int32_t merge, void* packed, const float* cos_t, con
  * q / o / dout / dq are [B,S,H,128] and k / v / dk / dv [B,S,HKV,128] through (batch, token, head) element strides;
  * lse fp32 [B,H,S] = log sum_j exp(scale * q.k_j) from the forward; dvec fp32 [B,H,S] is scratch (receives rowsum(dO*O)).
  * Two MFMA kernels (dQ; dK+dV), no atomics, bit-reproducible. */
-/* Forward of the same attention: out [B,S,H,128] (strides of q), lse fp32 [B,H,S]. */
+/* Forward of the same attention: out [B,S,H,128] (strides of q), lse fp32 [B,H,S].
+ * causal == 0 is the bidirectional form used when the vision towers train (HF CLIPAttention /
+ * Dinov2SelfAttention / timm Attention reached from clip_encoder.py:104, dino_encoder.py:159, siglip_encoder.py:97):
+ * every query sees keys [0, kv_len); rows [kv_len, S) are padding (S = kv_len rounded up to 128, zero-filled by the
+ * caller, head_dim zero-padded to 128) whose outputs / gradients are don't-care / zero. */
 int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t B, int64_t S, int32_t H, int32_t HKV,
                        int32_t hd, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
-                       float scale, void* out, float* lse, void* stream);
+                       float scale, int32_t causal, int64_t kv_len, void* out, float* lse, void* stream);
 int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                        int64_t B, int64_t S, int32_t H, int32_t HKV, int32_t hd,
                        int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
-                       float scale, float* dvec, void* dq, void* dk, void* dv, void* stream);
+                       float scale, int32_t causal, int64_t kv_len, float* dvec, void* dq, void* dk, void* dv, void* stream);
 /* Backward of h = silu(g) * u (Llama MLP gate; forward is cmb_act_mul with CMB_ACT_SILU):
  * dg = dh * u * silu'(g), du = dh * silu(g); all [rows, D] with row strides. */
 int cmb_swiglu_bwd(int dtype, const void* dh, int64_t lddh, const void* g, int64_t ldg, const void* u, int64_t ldu,

@@ -96,3 +96,26 @@ def test_flash_bwd_speed_vs_stock(dev):
         f_hip = timed_fwd(lambda: ops.causal_attention(q, k, v))
         f_ref = timed_fwd(lambda: F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=True))
     print(f"flash fwd B={B}: HIP {f_hip:.3f} ms vs stock SDPA forward (incl. K/V head expansion) {f_ref:.3f} ms")
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 17, 2, 64), (2, 577, 4, 64), (1, 729, 3, 72), (2, 730, 2, 64), (1, 256, 2, 128)])
+def test_vit_attention_bidirectional_padded(dev, B, N, H, hd):
+    """ops.vit_attention (trainable towers): the decoder's flash kernels in their non-causal form, any
+    token count (577 / 729 / 730) and head_dim (64 / 72) through zero padding + kv_len masking, forward and backward
+    against fp32 autograd."""
+    from cambrian_amd import ops
+    g_ = torch.Generator().manual_seed(N + hd)
+    q, k, v = (torch.randn(B, H, N, hd, generator=g_).to(torch.bfloat16).to(dev).requires_grad_() for _ in range(3))
+    w = torch.randn(B, H, N, hd, generator=g_).to(dev)
+    scale = hd ** -0.5
+    out = ops.vit_attention(q, k, v, scale)
+    assert out.shape == (B, H, N, hd)
+    qr, kr, vr = (t.detach().float().requires_grad_() for t in (q, k, v))
+    ref = torch.softmax(qr @ kr.transpose(-1, -2) * scale, -1) @ vr
+    assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < 2e-2
+    (out.float() * w).sum().backward()
+    (ref * w).sum().backward()
+    for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        assert a.shape == b.shape
+        err = ((a.float() - b).abs().max() / b.abs().max()).item()
+        assert err < 3e-2, f"{name}: rel err {err}"
