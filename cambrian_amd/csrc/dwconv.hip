@@ -179,6 +179,72 @@ int launch_dwconv_lds(const void* x, int64_t B, int H, int W, int C, const float
   return CMB_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the depthwise 7x7 (ConvNeXt towers that train):
+//   dW[t = dy*7+dx][c] = sum_{b,y,x} dY[b,y,x,c] * X[b, y+dy-3, x+dx-3, c]      (zero outside the map)
+// A workgroup owns a 64-channel slice and walks 8x8 output tiles (slot, slot + nslots, ...): the 14x14 input halo and
+// the 8x8 dY tile are staged in LDS (channel-contiguous rows -> coalesced 128-byte global reads), thread (c, rg) keeps
+// 49 fp32 accumulators over rows 2*rg, 2*rg+1 of every tile it sees.  The four row groups are summed through LDS at the
+// end and the slot's [49, 64] partial goes to `partial[slot][49][C]`; the caller column-sums the slots (cmb_colsum).
+// No atomics: bit-reproducible.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, int B,
+                                                              int H, int W, int C, float* __restrict__ partial) {
+  __shared__ float sx[14 * 14 * 64];   // halo tile, [row][col][channel]
+  __shared__ float sg[8 * 8 * 64];     // dY tile
+  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
+  const int c0 = blockIdx.y * 64;
+  const int tx = (W + 7) / 8, ty = (H + 7) / 8;
+  const int ntiles = B * ty * tx;
+  float acc[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (ty * tx), r = tile - b * ty * tx;
+    const int y0 = (r / tx) * 8, x0 = (r % tx) * 8;
+    __syncthreads();  // previous tile consumed
+    for (int i = tid; i < 14 * 14 * 64; i += 256) {
+      const int ch = i & 63, pos = i >> 6, py = pos / 14, px = pos - py * 14;
+      const int gy = y0 + py - 3, gx = x0 + px - 3;
+      float v = 0.f;
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        v = (float)x[(((int64_t)b * H + gy) * W + gx) * C + c0 + ch];
+      sx[i] = v;
+    }
+    for (int i = tid; i < 8 * 8 * 64; i += 256) {
+      const int ch = i & 63, pos = i >> 6, py = pos >> 3, px = pos & 7;
+      const int gy = y0 + py, gx = x0 + px;
+      float v = 0.f;
+      if (gy < H && gx < W) v = (float)dy[(((int64_t)b * H + gy) * W + gx) * C + c0 + ch];
+      sg[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry) {
+      const int py = 2 * rg + ry;
+      for (int px = 0; px < 8; ++px) {
+        const float g = sg[(py * 8 + px) * 64 + c];
+#pragma unroll
+        for (int dy_ = 0; dy_ < 7; ++dy_)
+#pragma unroll
+          for (int dx_ = 0; dx_ < 7; ++dx_) acc[dy_ * 7 + dx_] += g * sx[((py + dy_) * 14 + px + dx_) * 64 + c];
+      }
+    }
+  }
+  // sum the four row groups: [rg][49][64] through LDS (reuses the halo buffer: 4 * 49 * 64 floats <= 14 * 14 * 64)
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 49; ++t) sx[(rg * 49 + t) * 64 + c] = acc[t];
+  __syncthreads();
+  for (int i = tid; i < 49 * 64; i += 256) {
+    const float v = sx[i] + sx[49 * 64 + i] + sx[2 * 49 * 64 + i] + sx[3 * 49 * 64 + i];
+    const int t = i >> 6, ch = i & 63;
+    partial[((int64_t)blockIdx.x * 49 + t) * C + c0 + ch] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int cmb_dwconv7x7_nhwc(int dtype, const void* x, int64_t B, int64_t H, int64_t W, int64_t C,
@@ -201,6 +267,25 @@ extern "C" int cmb_dwconv7x7_nhwc(int dtype, const void* x, int64_t B, int64_t H
   else if (dtype == CMB_F32)
     hipLaunchKernelGGL((dwconv7x7_kernel<float, XT>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, B,
                        (int)H, (int)W, (int)C, w, bias, (float*)y);
+  else
+    return CMB_ERR_BAD_ARG;
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_dwconv7x7_wgrad(int dtype, const void* x, const void* dy, int64_t B, int64_t H, int64_t W, int64_t C,
+                                   float* partial, int32_t slots, void* stream) {
+  if (!x || !dy || !partial || B < 0 || H <= 0 || W <= 0 || C <= 0 || slots <= 0) return CMB_ERR_BAD_ARG;
+  if (C % 64 != 0) return CMB_ERR_SHAPE;
+  if (B == 0) return CMB_OK;
+  const dim3 grid((unsigned)slots, (unsigned)(C / 64));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CMB_BF16)
+    hipLaunchKernelGGL(dwconv7x7_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (int)B,
+                       (int)H, (int)W, (int)C, partial);
+  else if (dtype == CMB_F32)
+    hipLaunchKernelGGL(dwconv7x7_wgrad_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)dy, (int)B,
+                       (int)H, (int)W, (int)C, partial);
   else
     return CMB_ERR_BAD_ARG;
   CMB_CHECK_LAUNCH();

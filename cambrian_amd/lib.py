@@ -111,6 +111,7 @@ SIGNATURES = {
     "cmb_patchify_nchw": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _i32, C.c_int, _p, _i64, _p]),
     "cmb_patchify2x2_nhwc": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "cmb_dwconv7x7_nhwc": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p]),
+    "cmb_dwconv7x7_wgrad": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _i64, _i64, _p, _i32, _p]),
     "cmb_resample_bilinear": (C.c_int, [C.c_int, _p, _i64, _i32, _i32, _i64, _i64, _i64, _p, _i32, _i32, _i64, _i64, _p]),
     "cmb_act_mul": (C.c_int, [C.c_int, _i32, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_act_bwd": (C.c_int, [C.c_int, _i32, _p, _p, _i64, _p, _p]),

@@ -75,13 +75,17 @@ class CLIPConvNextTower(BaseVisionTower):
         else:
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
             canon = ConvNeXtTrunk.random_canonical(cfg, gen)
-        self.vision_tower = ConvNeXtTrunk(cfg, dtype).load_canonical(canon, self._target_device())
+        if self.unfreeze_mm_vision_tower:      # fp32 master parameters + autograd operators
+            from .convnext_train import TrainableConvNeXt
+            self.vision_tower = TrainableConvNeXt(cfg, canon, self._target_device(), dtype)
+        else:
+            self.vision_tower = ConvNeXtTrunk(cfg, dtype).load_canonical(canon, self._target_device())
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size), height=self._image_size,
                                                 width=self._image_size)
         self.is_loaded = True
 
     def _forward(self, images):
-        with torch.no_grad():
+        with self._grad_mode():  # clip_convnext_encoder.py:147: torch.set_grad_enabled(self.unfreeze_mm_vision_tower)
             side = None if self._interp_size is None else self.num_patches_per_side
             feats = self.vision_tower(images.to(device=self.device), side, multi_stage=self.is_multi_stage)
             return feats.to(images.dtype) if images.dtype in (torch.float32, torch.bfloat16) else feats

@@ -254,6 +254,12 @@ int cmb_patchify2x2_nhwc(int dtype, const void* x, int64_t B, int64_t H, int64_t
 /* Depthwise 7x7, pad 3, NHWC (timm ConvNeXtBlock.conv_dw): w [49, C] fp32 (tap-major), bias [C]. */
 int cmb_dwconv7x7_nhwc(int dtype, const void* x, int64_t B, int64_t H, int64_t W, int64_t C,
                        const float* w, const float* bias, void* y, void* stream);
+/* Weight gradient of that depthwise 7x7 (towers that train): every one of `slots` workgroup rows
+ * writes the partial sum over the 8x8 tiles it walked to partial[slot][49][C] (fp32); the caller column-sums the slots
+ * (cmb_colsum on [slots, 49*C]).  dX of the same layer is cmb_dwconv7x7_nhwc on dY with the taps reversed and a zero
+ * bias; d(bias) is a column sum of dY.  C % 64 == 0. */
+int cmb_dwconv7x7_wgrad(int dtype, const void* x, const void* dy, int64_t B, int64_t H, int64_t W, int64_t C,
+                        float* partial, int32_t slots, void* stream);
 /* Bilinear resample (align_corners=False, fp32 lerp) of a token grid, channels-last:
  * in [B, Hi*Wi, C] (row stride ld_in) -> out [B, Ho*Wo, ...] written at column offset into rows
  * of stride ld_out (so the 4 ConvNeXt stage maps land in one [B,9216,5760] buffer).

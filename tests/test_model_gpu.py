@@ -20,24 +20,34 @@ SIDE, S, P0, VH = 4, 64, 5, 1024
 
 
 class _SmallTower(nn.Module):
-    """Protocol-compatible stand-in with a small native trunk (the real ones are 0.3-1.1 B parameters)."""
+    """Protocol-compatible stand-in with a small native trunk (the real ones are 0.3-1.1 B parameters).  Kinds
+    'vit' / 'convnext' are the frozen trunks; 'vit_train' / 'convnext_train' the autograd ones."""
 
     def __init__(self, kind, dev, dt, seed):
         super().__init__()
         from cambrian_amd.model.multimodal_encoder.convnext import ConvNeXtConfig, ConvNeXtTrunk
         from cambrian_amd.model.multimodal_encoder.vit import ViTConfig, ViTTrunk
         gen = torch.Generator().manual_seed(seed)
-        self.kind = kind
+        self.trainable = kind.endswith("_train")
+        self.kind = kind = kind.replace("_train", "")
         if kind == "vit":   # 56 px / 14 -> 4x4 = 16 tokens
             self.cfg = ViTConfig(image_size=56, patch_size=14, hidden_size=128, num_layers=2, num_heads=2, mlp_dim=256,
                                  act="gelu", ln_eps=1e-6, has_cls=True, final_ln=True)
             self.canon = ViTTrunk.random_canonical(self.cfg, gen)
-            self.trunk = ViTTrunk(self.cfg, dt).load_canonical(self.canon, dev)
+            if self.trainable:
+                from cambrian_amd.model.multimodal_encoder.vit_train import TrainableViT
+                self.trunk = TrainableViT(self.cfg, self.canon, dev, dt)
+            else:
+                self.trunk = ViTTrunk(self.cfg, dt).load_canonical(self.canon, dev)
             self.hidden_size, self.res, self.tokens = 128, 56, 16
         else:               # 64 px -> stages 16/8/4/2 -> each resampled to 8x8 = 64 tokens, 64+128 channels... (4 stages)
             self.cfg = ConvNeXtConfig(depths=(1, 1, 1, 1), dims=(64, 64, 128, 128), ln_eps=1e-5)
             self.canon = ConvNeXtTrunk.random_canonical(self.cfg, gen)
-            self.trunk = ConvNeXtTrunk(self.cfg, dt).load_canonical(self.canon, dev)
+            if self.trainable:
+                from cambrian_amd.model.multimodal_encoder.convnext_train import TrainableConvNeXt
+                self.trunk = TrainableConvNeXt(self.cfg, self.canon, dev, dt)
+            else:
+                self.trunk = ConvNeXtTrunk(self.cfg, dt).load_canonical(self.canon, dev)
             self.hidden_size, self.res, self.tokens = 384, 64, 64
         self.is_loaded = True
 
@@ -45,16 +55,20 @@ class _SmallTower(nn.Module):
         pass
 
     def forward(self, images):
-        if self.kind == "vit":
-            from cambrian_amd.model.multimodal_encoder.vit import resample_tokens
-            return resample_tokens(self.trunk(images), self.tokens, force_copy=True)
-        return self.trunk(images, 8, multi_stage=True)
+        with torch.set_grad_enabled(self.trainable and torch.is_grad_enabled()):
+            if self.kind == "vit":
+                if self.trainable:
+                    return self.trunk(images)
+                from cambrian_amd.model.multimodal_encoder.vit import resample_tokens
+                return resample_tokens(self.trunk(images), self.tokens, force_copy=True)
+            return self.trunk(images, 8, multi_stage=True)
 
-    def oracle(self, images):
+    def oracle(self, images, canon=None):
         from oracle import towers as O
+        canon = self.canon if canon is None else canon
         if self.kind == "vit":
-            return O.vit_forward(self.cfg, self.canon, images)
-        return O.convnext_forward(self.cfg, self.canon, images, 8, multi_stage=True)
+            return O.vit_forward(self.cfg, canon, images)
+        return O.convnext_forward(self.cfg, canon, images, 8, multi_stage=True)
 
 
 def _build(dev, dt, monkeypatch, lm="llama", kinds=("vit", "convnext"), projector="sva", samplers=(2, 0, 2), p0=P0,
@@ -97,6 +111,9 @@ def _build(dev, dt, monkeypatch, lm="llama", kinds=("vit", "convnext"), projecto
     keys = ("mm_projector", "pos_emb", "vision_sampler", "vision_sampler_layers", "vision_query", "image_newline")
     for n, p in model.named_parameters():
         p.requires_grad_(any(k in n for k in keys))
+    if any(t.trainable for t in towers):
+        # --unfreeze_mm_vision_tower: towers become registered sub-modules (cambrian_arch.py:125-126) and train
+        model.model.vision_tower_aux_list = nn.ModuleList(towers)
     return model, cfg, towers
 
 
@@ -108,7 +125,12 @@ def _oracle_run(model, cfg, towers, batch):
         if k in train_names:
             p[k].requires_grad_()
     pm = {k[len("model."):]: v for k, v in p.items() if k.startswith("model.")}
-    feats = [t.oracle(img) for t, img in zip(towers, batch["images"])]
+    tower_p = [{k: v.detach().float().cpu().clone().requires_grad_(t.trainable) for k, v in t.canon.items()} for t in towers]
+    for i, tp in enumerate(tower_p):   # gradients of unfrozen towers are compared under "model.vision_tower_aux_list.i.trunk.p.<key>"
+        if towers[i].trainable:
+            for k, v in tp.items():
+                p[f"model.vision_tower_aux_list.{i}.trunk.p.{k.replace('.', '__')}"] = v
+    feats = [t.oracle(img, tp) for t, tp, img in zip(towers, tower_p, batch["images"])]
     emb, kv_final, mask_final, ctx_final = OA.prepare_inputs_static(pm, cfg, batch["input_ids"], feats,
                                                                     batch["image_aux_attention_masks_list"],
                                                                     pm["embed_tokens.weight"])
@@ -187,6 +209,8 @@ def _compare(dev, dt, model, cfg, towers, batch, tol_logits, tol_grad, min_check
         g_ref = p[n].grad
         if g_ref is None or g_ref.abs().max() == 0:
             continue
+        if n.endswith("k__bias"):   # key bias of a tower's attention: true gradient 0 (softmax shift invariance), noise only
+            continue
         err = rel_err(q.grad, g_ref)
         n_checked += 1
         if err > worst[1]:
@@ -237,6 +261,25 @@ def test_config34_hook_geometry_and_phi3_sva(dev, monkeypatch, lm, nkv, window):
     batch = synthetic_batch(2, seq_len=S, image_position=3, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
                             image_res=[56, 64], image_sizes=[(336, 336), (150, 336)], vocab_lo=1, vocab_hi=300)
     _compare(dev, dt, model, cfg, towers, batch, 1e-3, 5e-3, min_checked=50)
+
+
+def test_unfrozen_towers_end_to_end(dev, monkeypatch):
+    """``--unfreeze_mm_vision_tower`` — the loss back-propagates through the in-LLM SVA layers, the
+    connector and the aux projectors INTO the towers; every tower parameter's gradient against the fp32 oracle, and the
+    data-parallel bucket set covers the tower parameters."""
+    from cambrian_amd.train.data_layout import synthetic_batch
+    from cambrian_amd.train.dp import GradSync
+    dt = torch.bfloat16
+    model, cfg, towers = _build(dev, dt, monkeypatch, kinds=("vit_train", "convnext_train"))
+    names = [n for n, q in model.named_parameters() if q.requires_grad]
+    n_tower = sum("vision_tower_aux_list" in n for n in names)
+    assert n_tower > 80 and any("vision_sampler_layers" in n for n in names)
+    sync = GradSync([q for q in model.parameters() if q.requires_grad])
+    batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
+                            image_res=[56, 64], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
+    _compare(dev, dt, model, cfg, towers, batch, 5e-2, 2e-1, min_checked=50 + n_tower - 4)
+    sync.finish()
+    assert sum(len(b.params) for b in sync.buckets) == len(names)
 
 
 def test_config4_fp8_projection_gemms(dev, monkeypatch):

@@ -55,6 +55,55 @@ def test_trainable_vit_forward_and_all_parameter_gradients(dev, kind):
     assert worst[1] < 1.2e-1, f"worst tower-parameter gradient {worst}"
 
 
+def test_trainable_convnext_forward_and_all_parameter_gradients(dev):
+    from cambrian_amd.model.multimodal_encoder.convnext import ConvNeXtConfig, ConvNeXtTrunk
+    from cambrian_amd.model.multimodal_encoder.convnext_train import TrainableConvNeXt
+    from oracle import towers as O
+    cfg = ConvNeXtConfig(depths=(1, 1, 2, 1), dims=(64, 128, 256, 512), ln_eps=1e-5)
+    gen = torch.Generator().manual_seed(78)
+    canon = ConvNeXtTrunk.random_canonical(cfg, gen)
+    img = torch.randn(2, 3, 160, 160, generator=gen)           # stage maps 40 / 20 / 10 / 5: ragged 8x8 wgrad tiles
+    w = torch.randn(2, 144, 960, generator=gen)
+    p_ref = {k: v.clone().requires_grad_() for k, v in canon.items()}
+    ref = O.convnext_forward(cfg, p_ref, img, 12, multi_stage=True)
+    (ref * w).sum().backward()
+    tower = TrainableConvNeXt(cfg, canon, dev)
+    out = tower(img.to(dev), 12, multi_stage=True)
+    assert out.shape == ref.shape and rel_err(out, ref) < 5e-2
+    (out.float() * w.to(dev)).sum().backward()
+    worst = ("", 0.0)
+    for name, t in p_ref.items():
+        g = tower.P(name).grad
+        assert g is not None and t.grad is not None and t.grad.abs().max() > 0, name
+        e = rel_err(g, t.grad)
+        if e > worst[1]:
+            worst = (name, e)
+    assert len(tower.p) == len(p_ref) > 50
+    assert worst[1] < 1.2e-1, f"worst tower-parameter gradient {worst}"
+
+
+def test_dwconv_backward_kernels(dev):
+    """dX (forward kernel on dY with reversed taps), dW (cmb_dwconv7x7_wgrad + column sum) and d(bias) of the depthwise
+    7x7 against torch's conv2d autograd in fp32, on a ragged map."""
+    from cambrian_amd.model.multimodal_encoder.convnext_train import DwConv7x7Fn
+    import torch.nn.functional as F
+    B, H, W, C = 3, 19, 13, 128
+    g_ = torch.Generator().manual_seed(4)
+    x = torch.randn(B, H, W, C, generator=g_).to(dev).requires_grad_()
+    w49 = (torch.randn(49, C, generator=g_) * 0.2).to(dev).requires_grad_()
+    b = torch.randn(C, generator=g_).to(dev).requires_grad_()
+    dy = torch.randn(B, H, W, C, generator=g_).to(dev)
+    y = DwConv7x7Fn.apply(x, w49, b)
+    y.backward(dy)
+    xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w49, b))
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr.t().reshape(C, 1, 7, 7), br, padding=3, groups=C).permute(0, 2, 3, 1)
+    yr.backward(dy)
+    assert rel_err(y, yr.detach().cpu()) < 1e-5
+    assert rel_err(x.grad, xr.grad.cpu()) < 1e-5
+    assert rel_err(w49.grad, wr.grad.cpu()) < 1e-5
+    assert rel_err(b.grad, br.grad.cpu()) < 1e-5
+
+
 def test_trainable_vit_pos_fn_reaches_native_parameter(dev):
     """DINOv2: the 37x37 position grid is bicubically resized inside the forward; its gradient lands on the native rows."""
     from cambrian_amd.model.multimodal_encoder.dino_encoder import interpolate_pos_encoding
@@ -108,3 +157,15 @@ def test_unfrozen_wrapper_equals_frozen_wrapper_and_trains(dev):
     assert not torch.equal(before, train.vision_tower.P("layers.0.fc1.weight").detach())
     with torch.no_grad():
         assert not train(img).requires_grad
+
+
+def test_unfrozen_convnext_wrapper(dev):
+    from cambrian_amd.model.multimodal_encoder.clip_convnext_encoder import CLIPConvNextTower
+    from cambrian_amd.model.multimodal_encoder.convnext_train import TrainableConvNeXt
+    t = CLIPConvNextTower("clip-convnext-L-multi-stage-res256-interp144", SimpleNamespace(unfreeze_mm_vision_tower=True))
+    assert isinstance(t.vision_tower, TrainableConvNeXt) and sum(p.numel() for p in t.parameters()) > 1e8
+    img = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(2)).to(dev, torch.bfloat16)
+    f = t(img)
+    assert f.requires_grad and f.shape[:2] == (1, 144)
+    f.float().square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in t.parameters())
