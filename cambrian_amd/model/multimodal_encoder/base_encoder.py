@@ -120,12 +120,17 @@ class BaseVisionTower(nn.Module):
         return self._forward(images)
 
     # -- helpers ---------------------------------------------------------------------------------
-    def _make_vit(self, cfg, canon, dtype, pos_fn=None):
+    def _make_vit(self, cfg, canon, dtype, pos_fn=None, ref_keys=None):
         """Frozen: packed buffers + raw kernels, no graph (vit.py).  ``unfreeze_mm_vision_tower``: fp32 master
-        parameters + autograd operators (vit_train.py)."""
+        parameters + autograd operators (vit_train.py); ``ref_keys`` = (to_ref, from_ref) makes its
+        state_dict use the reference module's key names."""
         if self.unfreeze_mm_vision_tower:
             from .vit_train import TrainableViT
-            return TrainableViT(cfg, canon, self._target_device(), dtype, pos_fn=pos_fn)
+            trunk = TrainableViT(cfg, canon, self._target_device(), dtype, pos_fn=pos_fn)
+            if ref_keys is not None:
+                from .weight_maps import ReferenceKeys
+                ReferenceKeys(*ref_keys).install(trunk)
+            return trunk
         from .vit import ViTTrunk
         if pos_fn is not None:
             canon = dict(canon)

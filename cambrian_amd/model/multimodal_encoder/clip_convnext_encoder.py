@@ -77,7 +77,10 @@ class CLIPConvNextTower(BaseVisionTower):
             canon = ConvNeXtTrunk.random_canonical(cfg, gen)
         if self.unfreeze_mm_vision_tower:      # fp32 master parameters + autograd operators
             from .convnext_train import TrainableConvNeXt
+            from .weight_maps import ReferenceKeys, canonical_to_timm_convnext, timm_convnext_to_canonical as _from_timm
             self.vision_tower = TrainableConvNeXt(cfg, canon, self._target_device(), dtype)
+            ReferenceKeys(lambda p_: canonical_to_timm_convnext(p_, cfg.depths),           # keys of the timm trunk (:89)
+                          lambda sd_: _from_timm(sd_, cfg.depths)).install(self.vision_tower)
         else:
             self.vision_tower = ConvNeXtTrunk(cfg, dtype).load_canonical(canon, self._target_device())
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size), height=self._image_size,

@@ -71,12 +71,15 @@ class ClipVisionTower(BaseVisionTower):
             from .weight_maps import hf_clip_to_canonical
             sd = {k[len("vision_model."):] if k.startswith("vision_model.") else k: v
                   for k, v in load_checkpoint_state(ckpt).items() if not k.startswith(("text_model.", "text_projection", "logit_scale"))}
-            canon = hf_clip_to_canonical(sd, cfg.run_layers or cfg.num_layers)
+            # an unfrozen tower keeps (and checkpoints) all layers, the frozen trunk only those before select_layer
+            canon = hf_clip_to_canonical(sd, cfg.num_layers if self.unfreeze_mm_vision_tower else (cfg.run_layers or cfg.num_layers))
             logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
         else:
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
             canon = ViTTrunk.random_canonical(cfg, gen)
-        self.vision_tower = self._make_vit(cfg, canon, dtype)
+        from .weight_maps import canonical_to_hf_clip, hf_clip_to_canonical as _from_hf
+        self.vision_tower = self._make_vit(cfg, canon, dtype, ref_keys=(   # keys of HF CLIPVisionModel (clip_encoder.py:47)
+            lambda p_: canonical_to_hf_clip(p_, cfg.num_layers), lambda sd_: _from_hf(sd_, cfg.num_layers)))
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, flavour="hf"), height=self._image_size,
                                                 width=self._image_size)
         self.is_loaded = True

@@ -98,7 +98,11 @@ class DinoVisionTower(BaseVisionTower):
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
             canon = ViTTrunk.random_canonical(native, gen)
         # 37x37 -> e.g. 27x27 at 378 px: once at load when frozen, inside every forward (differentiably) when training
-        self.vision_tower = self._make_vit(run, canon, dtype, pos_fn=lambda pos: interpolate_pos_encoding(pos, run.grid))
+        from .weight_maps import canonical_to_hf_dinov2, hf_dinov2_to_canonical as _from_hf
+        sw = native.act == "swiglu"
+        self.vision_tower = self._make_vit(run, canon, dtype, pos_fn=lambda pos: interpolate_pos_encoding(pos, run.grid),
+                                           ref_keys=(lambda p_: canonical_to_hf_dinov2(p_, native.num_layers, sw),   # HF Dinov2Model
+                                                     lambda sd_: _from_hf(sd_, native.num_layers, sw)))
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, IMAGENET_MEAN, IMAGENET_STD, flavour="hf"),
                                                 height=self._image_size, width=self._image_size,
                                                 image_mean=IMAGENET_MEAN)

@@ -89,7 +89,9 @@ class SiglipVisionTower(ClipVisionTower):
         else:
             logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
             canon = ViTTrunk.random_canonical(cfg, gen)
-        self.vision_tower = self._make_vit(cfg, canon, dtype)
+        from .weight_maps import canonical_to_timm_vit, timm_vit_to_canonical as _from_timm
+        self.vision_tower = self._make_vit(cfg, canon, dtype, ref_keys=(   # keys of the timm trunk (siglip_encoder.py:55)
+            lambda p_: canonical_to_timm_vit(p_, cfg.num_layers), lambda sd_: _from_timm(sd_, cfg.num_layers)))
         self.image_processor = ProcessorWrapper(SimpleImageTransform(self._image_size, [0.5] * 3, [0.5] * 3),
                                                 height=self._image_size, width=self._image_size, image_mean=[0.5] * 3)
         self.is_loaded = True

@@ -66,15 +66,10 @@ class TrainableViT(nn.Module):
         self.cfg = cfg
         self.compute_dtype = dtype
         self.nl = cfg.run_layers if cfg.run_layers is not None else cfg.num_layers
-        keep = {}
-        for name, t in canonical.items():
-            if name.startswith("layers."):
-                if int(name.split(".")[1]) >= self.nl:
-                    continue                     # layers behind select_layer never run (clip_encoder.py:66)
-            if name.startswith("final_ln") and not cfg.final_ln:
-                continue
-            keep[_key(name)] = nn.Parameter(t.detach().to(device=device, dtype=torch.float32).clone())
-        self.p = nn.ParameterDict(keep)
+        # every tensor of the checkpoint stays a parameter — also the layers behind select_layer that never run
+        # (clip_encoder.py:66): they receive no gradient, exactly as in the reference, and survive a save / load
+        self.p = nn.ParameterDict({_key(name): nn.Parameter(t.detach().to(device=device, dtype=torch.float32).clone())
+                                   for name, t in canonical.items()})
 
     # ---- state under other naming schemes -----------------------------------------------------------------------
     def canonical_state(self) -> Dict[str, torch.Tensor]:
