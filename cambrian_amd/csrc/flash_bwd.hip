@@ -16,6 +16,7 @@
 // Layout: all of q, k, v, o, do, dq, dk, dv are addressed as [B, S, H, 128] through (batch, token, head) element strides
 // (token-major storage, what ops.qkv_rope produces and the attention returns); lse / D are fp32 [B, H, S].
 #include "common.h"
+#include "gemm_layout.h"
 
 namespace {
 
@@ -38,7 +39,47 @@ struct FlashParams {
   float scale;
 };
 
+// Block -> work mapping.  The hardware deals linear block ids round-robin to the 8 XCDs; with a (query block, head,
+// batch) grid every XCD would get two fixed query blocks of each head — under the causal mask XCD 0 then carries 2.4x
+// the tiles of XCD 7.  Instead the grid is 1-D and an XCD owns a contiguous range of (batch, KV head) groups: all query
+// blocks (heavy and light) and all query heads of a group run on one XCD, which balances the causal triangle and keeps
+// the group's K / V in that XCD's L2.  Within a group the heaviest blocks come first.
+struct FlashBlock {
+  int b, hk, h, blk;
+};
+__device__ __forceinline__ FlashBlock flash_block_qh(const int S, const int H, const int HKV) {  // one (query block, head)
+  const int nqb = S / 128, group = H / HKV, per = nqb * group;
+  const int id = gl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int gi = id / per, w = id - gi * per;
+  FlashBlock f;
+  f.b = gi / HKV; f.hk = gi - f.b * HKV;
+  f.blk = nqb - 1 - w / group;   // latest (heaviest under the causal mask) query blocks first
+  f.h = f.hk * group + w % group;
+  return f;
+}
+__device__ __forceinline__ FlashBlock flash_block_kv(const int S, const int HKV) {  // one (key block, KV head)
+  const int nkb = S / 128;
+  const int id = gl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int gi = id / nkb;
+  FlashBlock f;
+  f.b = gi / HKV; f.hk = gi - f.b * HKV; f.h = 0;
+  f.blk = id - gi * nkb;         // key block 0 sees every query tile: heaviest first
+  return f;
+}
+
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// 8 fp32 -> 8 bf16 with four v_cvt_pk_bf16_f32 (a scalar (bf16_t)x per element costs a convert + a permute each)
+__device__ __forceinline__ bf16x8_t cvt8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+  const f32x2_t v0 = {a0, a1}, v1 = {a2, a3}, v2 = {a4, a5}, v3 = {a6, a7};
+  const u32x4_t w = {__builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2_t)),
+                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2_t)),
+                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_t)),
+                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v3, bf16x2_t))};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
 
 // D[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]: one wave per (token, head) row, 2 elements per lane
 __global__ void __launch_bounds__(256) flash_dvec_kernel(const FlashParams p) {
@@ -58,35 +99,48 @@ __global__ void __launch_bounds__(256) flash_dvec_kernel(const FlashParams p) {
   }
 }
 
-// stage a 64-row x 128 tile (rows of `src` with element stride `rs`) into a row-major LDS image (stride LDR) and,
-// if TR, also into the transposed image [128][LDT] (pairs of adjacent rows packed as one 32-bit store).
-template <bool ROWMAJOR, bool TR>
-__device__ __forceinline__ void stage_tile64(const bf16_t* src, int64_t rs, int row0, int nrows_valid, bf16_t* sR,
-                                             bf16_t* sT, int tid) {
-  // 64 rows x 16 vec8 = 1024 vec8 -> 4 per thread; thread handles row pair (2*rp, 2*rp+1), d-group dg for the
-  // transposed image so that both rows of a pair are in one thread
+// A 64-row x 128 tile moves global -> registers -> LDS in two halves so that the global loads of the NEXT tile can be
+// in flight while the current one is being multiplied (tile_load after the barrier that publishes the current tile,
+// tile_put after the barrier that retires it).  Thread <-> (row pair rp, d group dg) x 2 passes: 4 consecutive lanes
+// cover 64 contiguous bytes of a row (global coalescing), 16 lane groups take consecutive row pairs (the transposed
+// 32-bit stores then hit consecutive banks, 2-way at most: free for ds_write_b32).
+struct TileRegs {
+  bf16x8_t a[2], b[2];
+};
+
+__device__ __forceinline__ void tile_load(TileRegs& r, const bf16_t* src, int64_t rs, int row0, int nrows_valid, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    // 4 consecutive lanes cover 64 contiguous bytes of a row (global coalescing), 16 lane groups take consecutive row
-    // pairs (the transposed 32-bit stores then hit consecutive banks, 2-way at most: free for ds_write_b32)
     const int id = tid + 256 * i;       // 0..511
     const int dg = ((id >> 6) & 3) * 4 + (id & 3);     // d group 0..15
     const int rp = (id >> 8) * 16 + ((id >> 2) & 15);  // row pair 0..31
     int r0 = row0 + 2 * rp, r1 = r0 + 1;
     r0 = r0 < nrows_valid ? r0 : nrows_valid - 1;
     r1 = r1 < nrows_valid ? r1 : nrows_valid - 1;
-    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(src + (int64_t)r0 * rs + dg * 8);
-    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(src + (int64_t)r1 * rs + dg * 8);
+    r.a[i] = *reinterpret_cast<const bf16x8_t*>(src + (int64_t)r0 * rs + dg * 8);
+    r.b[i] = *reinterpret_cast<const bf16x8_t*>(src + (int64_t)r1 * rs + dg * 8);
+  }
+}
+
+// row-major LDS image (stride LDR) and / or the transposed image [128][LDT] (pairs of adjacent rows packed as one
+// 32-bit store)
+template <bool ROWMAJOR, bool TR>
+__device__ __forceinline__ void tile_put(const TileRegs& r, bf16_t* sR, bf16_t* sT, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + 256 * i;
+    const int dg = ((id >> 6) & 3) * 4 + (id & 3);
+    const int rp = (id >> 8) * 16 + ((id >> 2) & 15);
     if (ROWMAJOR) {
-      *reinterpret_cast<bf16x8_t*>(sR + (2 * rp) * LDR + dg * 8) = a;
-      *reinterpret_cast<bf16x8_t*>(sR + (2 * rp + 1) * LDR + dg * 8) = b;
+      *reinterpret_cast<bf16x8_t*>(sR + (2 * rp) * LDR + dg * 8) = r.a[i];
+      *reinterpret_cast<bf16x8_t*>(sR + (2 * rp + 1) * LDR + dg * 8) = r.b[i];
     }
     if (TR) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         bf16x2_t pr;
-        pr[0] = a[e];
-        pr[1] = b[e];
+        pr[0] = r.a[i][e];
+        pr[1] = r.b[i][e];
         *reinterpret_cast<bf16x2_t*>(sT + (dg * 8 + e) * LDT + 2 * rp) = pr;
       }
     }
@@ -94,7 +148,7 @@ __device__ __forceinline__ void stage_tile64(const bf16_t* src, int64_t rs, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Forward: grid (S/128, H, B), 256 threads, a lane owns one query (the dQ kernel's arrangement): S^T = K·Q^T from the
+// Forward: grid S/128 * H * B (1-D, flash_block_qh), 256 threads, a lane owns one query (the dQ kernel's arrangement): S^T = K·Q^T from the
 // row-major K tile, online softmax in base 2 (row max / sum need one lane^32 exchange), O^T += V^T·P^T with P going
 // accumulator -> operand without shuffles and V^T fragments from the transposed V image.  K/V heads are shared by the
 // query heads of a group without being expanded.  Writes O (bf16) and lse = log sum_j exp(scale q.k_j) (fp32).
@@ -106,9 +160,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
   __shared__ __attribute__((aligned(16))) bf16_t sVT[HD * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int hk = h / (p.H / p.HKV);
-  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const FlashBlock fb = flash_block_qh(p.S, p.H, p.HKV);
+  const int b = fb.b, h = fb.h, hk = fb.hk, qb = fb.blk;
   const int q0 = qb * 128 + wave * 32;
   const int qi = q0 + j;
   const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
@@ -125,11 +178,18 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   const int nt = CAUSAL ? (qb * 128 + 128) / 64 : (p.kv_len + 63) / 64;
+  TileRegs rk, rv;
+  tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
+  tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
   for (int t = 0; t < nt; ++t) {
+    __syncthreads();  // previous tile consumed
+    tile_put<true, false>(rk, sK, nullptr, tid);
+    tile_put<false, true>(rv, nullptr, sVT, tid);
     __syncthreads();
-    stage_tile64<true, false>(kbase, p.kv_ss, t * 64, p.S, sK, nullptr, tid);
-    stage_tile64<false, true>(vbase, p.kv_ss, t * 64, p.S, nullptr, sVT, tid);
-    __syncthreads();
+    if (t + 1 < nt) {  // the next tile's loads fly during this tile's MFMAs
+      tile_load(rk, kbase, p.kv_ss, (t + 1) * 64, p.S, tid);
+      tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
+    }
     if (CAUSAL && t * 64 > q0 + 31) continue;
     f32x16_t s[2];
 #pragma unroll
@@ -142,39 +202,48 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
       }
     }
+    // VALU budget: this block runs once per 32 MFMAs of the wave, so every instruction per score element counts.
+    // The mask is applied only on tiles that can hold a masked key for some query of the wave (the diagonal tiles /
+    // the tile with the padding), scores stay un-scaled until the exponent (one fma per element feeds exp2), the
+    // accumulators are rescaled only when some lane's running maximum moved, P is converted two elements at a time.
+    if (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[kt][r] = -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float v = (CAUSAL ? key <= qi : key < p.kv_len) ? s[kt][r] * c2 : -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;   // c2 > 0: max of the scaled scores
     const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+    }
     m = m_new;
-    l *= alpha;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, -m_new));
         l += pv;
         s[kt][r] = pv;
       }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int kt = kb >> 1, hh = kb & 1;
-      bf16x8_t pf;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kt][8 * hh + e];
+      const bf16x8_t pf = cvt8(s[kt][8 * hh + 0], s[kt][8 * hh + 1], s[kt][8 * hh + 2], s[kt][8 * hh + 3],
+                               s[kt][8 * hh + 4], s[kt][8 * hh + 5], s[kt][8 * hh + 6], s[kt][8 * hh + 7]);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const bf16_t* vrow = sVT + (d * 32 + j) * LDT + kt * 32 + 16 * hh + 4 * g;
@@ -203,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dQ: grid (S/128, H, B), 256 threads.  lane = (query j = lane & 31 of the wave's 32, half g = lane >> 5).
+// dQ: grid S/128 * H * B (1-D, flash_block_qh), 256 threads.  lane = (query j = lane & 31 of the wave's 32, half g = lane >> 5).
 // ------------------------------------------------------------------------------------------------------------------
 template <bool CAUSAL>
 __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const FlashParams p) {
@@ -212,9 +281,8 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
   __shared__ __attribute__((aligned(16))) bf16_t sKT[HD * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int hk = h / (p.H / p.HKV);
-  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;  // heaviest (latest) query blocks first
+  const FlashBlock fb = flash_block_qh(p.S, p.H, p.HKV);
+  const int b = fb.b, h = fb.h, hk = fb.hk, qb = fb.blk;
   const int q0 = qb * 128 + wave * 32;
   const int qi = q0 + j;                                  // this lane's query (S % 128 == 0: always valid)
   const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
@@ -239,11 +307,18 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
 
   const int nt = CAUSAL ? (qb * 128 + 128) / 64   // key tiles up to and including the diagonal ones
                         : (p.kv_len + 63) / 64;   // every tile that holds a real key
+  TileRegs rk, rv;
+  tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
+  tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // previous tile fully consumed
-    stage_tile64<true, true>(kbase, p.kv_ss, t * 64, p.S, sK, sKT, tid);
-    stage_tile64<true, false>(vbase, p.kv_ss, t * 64, p.S, sV, nullptr, tid);
+    tile_put<true, true>(rk, sK, sKT, tid);
+    tile_put<true, false>(rv, sV, nullptr, tid);
     __syncthreads();
+    if (t + 1 < nt) {  // the next tile's loads fly during this tile's MFMAs
+      tile_load(rk, kbase, p.kv_ss, (t + 1) * 64, p.S, tid);
+      tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
+    }
     if (CAUSAL && t * 64 > q0 + 31) continue;  // whole tile above this wave's diagonal (block-uniform barriers stay matched)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -257,17 +332,23 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T[key][query]
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T[key][query]
       }
+      // mask only where the tile can hold a masked key for some query of the wave; one fma feeds exp2
+      if (CAUSAL ? (t * 64 + kt * 32 + 31 > q0) : (t * 64 + kt * 32 + 32 > p.kv_len)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[r] = -INFINITY;   // exp2(-inf) = 0
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float pr = (CAUSAL ? key <= qi : key < p.kv_len) ? __builtin_amdgcn_exp2f(s[r] * c2 - lse2) : 0.f;
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lse2));
         s[r] = pr * (dp[r] - dq_d);  // dS^T (the 1/sqrt(d) factor is applied once at the end)
       }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        bf16x8_t pf;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[8 * kb + e];
+        const bf16x8_t pf = cvt8(s[8 * kb + 0], s[8 * kb + 1], s[8 * kb + 2], s[8 * kb + 3], s[8 * kb + 4], s[8 * kb + 5],
+                                 s[8 * kb + 6], s[8 * kb + 7]);
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
           const bf16_t* trow = sKT + (d * 32 + j) * LDT + kt * 32 + 16 * kb + 4 * g;
@@ -294,7 +375,7 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dK, dV: grid (S/128, HKV, B), 256 threads.  lane = (key j of the wave's 32, half g).  One workgroup per CU (the
+// dK, dV: grid S/128 * HKV * B (1-D, flash_block_kv), 256 threads.  lane = (key j of the wave's 32, half g).  One workgroup per CU (the
 // accumulators + K/V fragments need ~350 registers), so the HBM/L2 latency of the next query tile is hidden inside the
 // workgroup by a register prefetch (see the loop).  (A double-buffered-LDS variant with one barrier per tile measured
 // slower: 506 registers, values shuffled through the accumulator file.)
@@ -310,8 +391,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   float* sD = sLse + 64;                                    // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
-  const int b = blockIdx.z, hk = blockIdx.y;
-  const int kb = blockIdx.x;  // key blocks in natural order: block 0 sees every query tile (heaviest first)
+  const FlashBlock fb = flash_block_kv(p.S, p.HKV);
+  const int b = fb.b, hk = fb.hk, kb = fb.blk;
   const int k0 = kb * 128 + wave * 32;
   const int ki = k0 + j;
   const int group = p.H / p.HKV;
@@ -399,6 +480,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[ks], dp, 0, 0, 0);  // dP[query][key]
         }
         f32x16_t pr;
+        // mask only where some key of the wave can be masked for some query of this 32-row half tile
+        const bool edge = CAUSAL ? (k0 + 31 > qt * 64 + qs * 32) : (k0 + 32 > p.kv_len);
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int qrow = qs * 32 + 8 * r4 + 4 * g;  // rows qrow .. qrow+3 <-> registers 4*r4 .. 4*r4+3
@@ -407,20 +490,20 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * r4 + e;
-            const int qidx = qt * 64 + qrow + e;
-            const float pv = (CAUSAL ? ki <= qidx : ki < p.kv_len) ? __builtin_amdgcn_exp2f(s[r] * c2 - l4[e]) : 0.f;
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -l4[e]));
+            if (edge) {
+              const int qidx = qt * 64 + qrow + e;
+              if (!(CAUSAL ? ki <= qidx : ki < p.kv_len)) pv = 0.f;
+            }
             pr[r] = pv;
             s[r] = pv * (dp[r] - d4[e]);  // dS
           }
         }
 #pragma unroll
         for (int qb16 = 0; qb16 < 2; ++qb16) {
-          bf16x8_t pf, dsf;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pf[e] = (bf16_t)pr[8 * qb16 + e];
-            dsf[e] = (bf16_t)s[8 * qb16 + e];
-          }
+          const int o8 = 8 * qb16;
+          const bf16x8_t pf = cvt8(pr[o8], pr[o8 + 1], pr[o8 + 2], pr[o8 + 3], pr[o8 + 4], pr[o8 + 5], pr[o8 + 6], pr[o8 + 7]);
+          const bf16x8_t dsf = cvt8(s[o8], s[o8 + 1], s[o8 + 2], s[o8 + 3], s[o8 + 4], s[o8 + 5], s[o8 + 6], s[o8 + 7]);
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
             const bf16_t* grow = sDOT + (d * 32 + j) * LDT + qs * 32 + 16 * qb16 + 4 * g;
@@ -482,7 +565,7 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(flash_dvec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   }
-  const dim3 gq((unsigned)(S / 128), (unsigned)H, (unsigned)B), gk((unsigned)(S / 128), (unsigned)HKV, (unsigned)B);
+  const dim3 gq((unsigned)((S / 128) * H * B)), gk((unsigned)((S / 128) * HKV * B));   // 1-D: see flash_block_*
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
@@ -518,7 +601,7 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.dq = p.dk = p.dv = nullptr; p.lse = nullptr; p.dvec = nullptr;
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
-  const dim3 grid((unsigned)(S / 128), (unsigned)H, (unsigned)B);
+  const dim3 grid((unsigned)((S / 128) * H * B));   // 1-D: see flash_block_qh
   if (causal)
     hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
   else
