@@ -47,23 +47,22 @@ struct FlashParams {
 struct FlashBlock {
   int b, hk, h, blk;
 };
-__device__ __forceinline__ FlashBlock flash_block_qh(const int S, const int H, const int HKV) {  // one (query block, head)
-  const int nqb = S / 128, group = H / HKV, per = nqb * group;
+__device__ __forceinline__ FlashBlock flash_block_qh(const int nqb, const int H, const int HKV) {  // nqb work items per head
+  const int group = H / HKV, per = nqb * group;
   const int id = gl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int gi = id / per, w = id - gi * per;
   FlashBlock f;
   f.b = gi / HKV; f.hk = gi - f.b * HKV;
-  f.blk = nqb - 1 - w / group;   // latest (heaviest under the causal mask) query blocks first
+  f.blk = w / group;
   f.h = f.hk * group + w % group;
   return f;
 }
-__device__ __forceinline__ FlashBlock flash_block_kv(const int S, const int HKV) {  // one (key block, KV head)
-  const int nkb = S / 128;
+__device__ __forceinline__ FlashBlock flash_block_kv(const int per, const int HKV) {  // `per` work items per (batch, KV head)
   const int id = gl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int gi = id / nkb;
+  const int gi = id / per;
   FlashBlock f;
   f.b = gi / HKV; f.hk = gi - f.b * HKV; f.h = 0;
-  f.blk = id - gi * nkb;         // key block 0 sees every query tile: heaviest first
+  f.blk = id - gi * per;
   return f;
 }
 
@@ -160,8 +159,14 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
   __shared__ __attribute__((aligned(16))) bf16_t sVT[HD * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
-  const FlashBlock fb = flash_block_qh(p.S, p.H, p.HKV);
-  const int b = fb.b, h = fb.h, hk = fb.hk, qb = fb.blk;
+  // Causal: query block qb walks (qb + 1) * 2 key tiles, so a workgroup takes the PAIR (i, nqb-1-i) one after the
+  // other — uniform work per workgroup, no tail.
+  const int nqb = p.S / 128;
+  const FlashBlock fb = flash_block_qh(CAUSAL ? (nqb + 1) / 2 : nqb, p.H, p.HKV);
+  const int b = fb.b, h = fb.h, hk = fb.hk;
+  const int nrep = (CAUSAL && fb.blk != nqb - 1 - fb.blk) ? 2 : 1;
+  for (int rep = 0; rep < nrep; ++rep) {
+  const int qb = rep == 0 ? nqb - 1 - fb.blk : fb.blk;
   const int q0 = qb * 128 + wave * 32;
   const int qi = q0 + j;
   const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
@@ -269,6 +274,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
       *reinterpret_cast<bf16x4_t*>(orow + d * 32 + 8 * qd + 4 * g) = o;
     }
   if (g == 0) lse_out[((int64_t)b * p.H + h) * p.S + qi] = (m + __builtin_amdgcn_logf(l_tot)) * (1.0f / LOG2E);
+  }  // rep
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -281,8 +287,12 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
   __shared__ __attribute__((aligned(16))) bf16_t sKT[HD * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
-  const FlashBlock fb = flash_block_qh(p.S, p.H, p.HKV);
-  const int b = fb.b, h = fb.h, hk = fb.hk, qb = fb.blk;
+  const int nqb = p.S / 128;   // causal: pairs (i, nqb-1-i), as in the forward
+  const FlashBlock fb = flash_block_qh(CAUSAL ? (nqb + 1) / 2 : nqb, p.H, p.HKV);
+  const int b = fb.b, h = fb.h, hk = fb.hk;
+  const int nrep = (CAUSAL && fb.blk != nqb - 1 - fb.blk) ? 2 : 1;
+  for (int rep = 0; rep < nrep; ++rep) {
+  const int qb = rep == 0 ? nqb - 1 - fb.blk : fb.blk;
   const int q0 = qb * 128 + wave * 32;
   const int qi = q0 + j;                                  // this lane's query (S % 128 == 0: always valid)
   const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
@@ -372,10 +382,11 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
       for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[d][4 * qd + e] * p.scale);
       *reinterpret_cast<bf16x4_t*>(out + d * 32 + 8 * qd + 4 * g) = o;
     }
+  }  // rep
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// dK, dV: grid S/128 * HKV * B (1-D, flash_block_kv), 256 threads.  lane = (key j of the wave's 32, half g).  One workgroup per CU (the
+// dK, dV: grid (key-block pairs | key blocks) * HKV * B (1-D, flash_block_kv), 256 threads.  lane = (key j of the wave's 32, half g).  One workgroup per CU (the
 // accumulators + K/V fragments need ~350 registers), so the HBM/L2 latency of the next query tile is hidden inside the
 // workgroup by a register prefetch (see the loop).  (A double-buffered-LDS variant with one barrier per tile measured
 // slower: 506 registers, values shuffled through the accumulator file.)
@@ -391,8 +402,14 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   float* sD = sLse + 64;                                    // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
-  const FlashBlock fb = flash_block_kv(p.S, p.HKV);
-  const int b = fb.b, hk = fb.hk, kb = fb.blk;
+  // Causal: key block kb meets (nkb - kb) * 2 query tiles per head, so a workgroup takes the PAIR (i, nkb-1-i) one
+  // after the other — every workgroup does the same amount of work and the grid has no tail.
+  const int nkb = p.S / 128;
+  const FlashBlock fb = flash_block_kv(CAUSAL ? (nkb + 1) / 2 : nkb, p.HKV);
+  const int b = fb.b, hk = fb.hk;
+  const int nrep = (CAUSAL && fb.blk != nkb - 1 - fb.blk) ? 2 : 1;
+  for (int rep = 0; rep < nrep; ++rep) {
+  const int kb = rep == 0 ? fb.blk : nkb - 1 - fb.blk;
   const int k0 = kb * 128 + wave * 32;
   const int ki = k0 + j;
   const int group = p.H / p.HKV;
@@ -539,6 +556,7 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
       *reinterpret_cast<bf16x4_t*>(okr + d * 32 + 8 * qd + 4 * g) = a;
       *reinterpret_cast<bf16x4_t*>(ovr + d * 32 + 8 * qd + 4 * g) = c;
     }
+  }  // rep
 }
 
 }  // namespace
@@ -565,7 +583,8 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
     if (blocks > 65535) blocks = 65535;
     hipLaunchKernelGGL(flash_dvec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
   }
-  const dim3 gq((unsigned)((S / 128) * H * B)), gk((unsigned)((S / 128) * HKV * B));   // 1-D: see flash_block_*
+  const int64_t nkb = S / 128;
+  const dim3 gq((unsigned)((causal ? (nkb + 1) / 2 : nkb) * H * B)), gk((unsigned)((causal ? (nkb + 1) / 2 : nkb) * HKV * B));   // 1-D: see flash_block_*
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
@@ -601,7 +620,8 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.dq = p.dk = p.dv = nullptr; p.lse = nullptr; p.dvec = nullptr;
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
-  const dim3 grid((unsigned)((S / 128) * H * B));   // 1-D: see flash_block_qh
+  const int64_t nqb = S / 128;
+  const dim3 grid((unsigned)((causal ? (nqb + 1) / 2 : nqb) * H * B));   // 1-D: see flash_block_qh
   if (causal)
     hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
   else
