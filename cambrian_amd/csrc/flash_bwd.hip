@@ -10,8 +10,8 @@
 //   * flash_dkdv_kernel — a workgroup owns 128 keys of one (batch, KV head), a LANE owns one key and walks the query
 //     tiles from the diagonal on, for the 4 query heads of the group:  S = Q·K^T, dP = dO·V^T (Q, dO rows from LDS, K,
 //     V fragments in registers), dV^T += dO^T·P, dK^T += Q^T·dS (transposed Q / dO images in LDS).
-// P is recomputed from the forward's log-sum-exp (natural log of the sum of exp(scale·q·k)); D = rowsum(dO∘O) comes
-// from a small pre-pass.  7 tile products instead of the 5 of a single-pass backward, nothing is atomically
+// P is recomputed from the forward's log-sum-exp (natural log of the sum of exp(scale·q·k)); D = rowsum(dO∘O) is computed
+// in the dQ kernel's prologue (each lane owns a query row) and handed to the dK/dV kernel through dvec.  7 tile products instead of the 5 of a single-pass backward, nothing is atomically
 // accumulated, results are bit-reproducible.
 // Layout: all of q, k, v, o, do, dq, dk, dv are addressed as [B, S, H, 128] through (batch, token, head) element strides
 // (token-major storage, what ops.qkv_rope produces and the attention returns); lse / D are fp32 [B, H, S].
@@ -78,24 +78,6 @@ __device__ __forceinline__ bf16x8_t cvt8(float a0, float a1, float a2, float a3,
                      __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_t)),
                      __builtin_bit_cast(uint32_t, __builtin_convertvector(v3, bf16x2_t))};
   return __builtin_bit_cast(bf16x8_t, w);
-}
-
-// D[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]: one wave per (token, head) row, 2 elements per lane
-__global__ void __launch_bounds__(256) flash_dvec_kernel(const FlashParams p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t rows = (int64_t)p.B * p.S * p.H;
-  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
-    const int h = (int)(r % p.H);
-    const int64_t bs = r / p.H;
-    const int s = (int)(bs % p.S);
-    const int64_t b = bs / p.S;
-    const int64_t off = b * p.q_sb + (int64_t)s * p.q_ss + (int64_t)h * p.q_sh + lane * 2;
-    const bf16x2_t a = *reinterpret_cast<const bf16x2_t*>(p.o + off);
-    const bf16x2_t g = *reinterpret_cast<const bf16x2_t*>(p.dout + off);
-    float d = (float)a[0] * (float)g[0] + (float)a[1] * (float)g[1];
-    d = wave_sum(d);
-    if (lane == 0) p.dvec[(b * p.H + h) * (int64_t)p.S + s] = d;
-  }
 }
 
 // A 64-row x 128 tile moves global -> registers -> LDS in two halves so that the global loads of the NEXT tile can be
@@ -304,7 +286,22 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
     dof[ks] = *reinterpret_cast<const bf16x8_t*>(dorow + ks * 16 + g * 8);
   }
   const int64_t st = ((int64_t)b * p.H + h) * p.S + qi;
-  const float lse2 = p.lse[st] * LOG2E, dq_d = p.dvec[st];
+  // D = rowsum(dO * O) of this lane's query: the lane holds half of the dO row (the other half sits in lane ^ 32), so the
+  // O row is read once here and D also goes to dvec for the dK/dV kernel, which runs after this one on the stream —
+  // no separate pre-pass over O and dO.
+  float dq_d = 0.f;
+  {
+    const bf16_t* orow = p.o + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(orow + ks * 16 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dq_d += (float)of[e] * (float)dof[ks][e];
+    }
+    dq_d += __shfl_xor(dq_d, 32, 64);
+    if (g == 0) p.dvec[st] = dq_d;
+  }
+  const float lse2 = p.lse[st] * LOG2E;
   const float c2 = p.scale * LOG2E;
   const bf16_t* kbase = p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
   const bf16_t* vbase = p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
@@ -578,11 +575,6 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
   hipStream_t s = (hipStream_t)stream;
-  {
-    int64_t rows = B * S * H, blocks = (rows + 3) / 4;
-    if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(flash_dvec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  }
   const int64_t nkb = S / 128;
   const dim3 gq((unsigned)((causal ? (nkb + 1) / 2 : nkb) * H * B)), gk((unsigned)((causal ? (nkb + 1) / 2 : nkb) * HKV * B));   // 1-D: see flash_block_*
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;

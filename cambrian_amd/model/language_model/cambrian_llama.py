@@ -79,6 +79,15 @@ def _fused_frozen_weight(owner: nn.Module, key: str, mods) -> Optional[torch.Ten
     return cached[1]
 
 
+def _down_proj(lin: nn.Linear, inner: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
+    if residual is None:
+        return lin(inner)
+    if lin.bias is not None or not residual.is_contiguous():
+        return residual + lin(inner)
+    H = residual.shape[-1]
+    return torch.addmm(residual.view(-1, H), inner.reshape(-1, inner.shape[-1]), lin.weight.t()).view_as(residual)
+
+
 class LlamaMLP(nn.Module):
     def __init__(self, cfg, device, dtype):
         super().__init__()
@@ -87,11 +96,15 @@ class LlamaMLP(nn.Module):
         self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, **kw)
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, **kw)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual``: the layer's skip connection — added by the down-projection GEMM itself (C = residual, beta = 1)
+        instead of a separate elementwise pass over [tokens, hidden]."""
         w_gu = _fused_frozen_weight(self, "_w_gate_up", (self.gate_proj, self.up_proj))
         if w_gu is not None and x.is_cuda:
-            return self.down_proj(ops.swiglu_packed(F.linear(x, w_gu)))
-        return self.down_proj(ops.swiglu(self.gate_proj(x), self.up_proj(x)))
+            inner = ops.swiglu_packed(F.linear(x, w_gu))
+        else:
+            inner = ops.swiglu(self.gate_proj(x), self.up_proj(x))
+        return _down_proj(self.down_proj, inner, residual)
 
 
 class LlamaAttention(nn.Module):
@@ -154,7 +167,7 @@ class LlamaDecoderLayer(nn.Module):
         a = self.self_attn(self.input_layernorm(x), cos, sin, attn_mask, kv_out)
         n2 = self.post_attention_layernorm
         x, h = ops.add_rmsnorm(x, a, n2.weight, n2.variance_epsilon)  # x + a and norm(x + a) in one pass
-        return x + self.mlp(h)
+        return self.mlp(h, residual=x)
 
     def decode(self, x, cos, sin, kcache, vcache, t, key_mask):
         x = x + self.self_attn.decode(self.input_layernorm(x), cos, sin, kcache, vcache, t, key_mask)

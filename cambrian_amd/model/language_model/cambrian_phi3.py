@@ -32,7 +32,7 @@ except Exception:  # pragma: no cover
 
 from ... import lib as L
 from ... import ops
-from .cambrian_llama import CambrianLlamaForCausalLM, CambrianLlamaModel, HipRMSNorm
+from .cambrian_llama import CambrianLlamaForCausalLM, CambrianLlamaModel, HipRMSNorm, _down_proj
 
 
 class CambrianConfig(Phi3Config):
@@ -60,8 +60,9 @@ class Phi3MLP(nn.Module):
         self.gate_up_proj = nn.Linear(cfg.hidden_size, 2 * cfg.intermediate_size, **kw)
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, **kw)
 
-    def forward(self, x):
-        return self.down_proj(ops.swiglu_packed(self.gate_up_proj(x)))          # up * silu(gate), :303-308
+    def forward(self, x, residual=None):
+        inner = ops.swiglu_packed(self.gate_up_proj(x))                          # up * silu(gate), :303-308
+        return _down_proj(self.down_proj, inner, residual)                       # skip connection folded into the GEMM
 
 
 class Phi3Attention(nn.Module):
@@ -109,7 +110,7 @@ class Phi3DecoderLayer(nn.Module):
         a = self.self_attn(self.input_layernorm(x), cos, sin, attn_mask, kv_out)
         n2 = self.post_attention_layernorm
         x, h = ops.add_rmsnorm(x, a, n2.weight, n2.variance_epsilon)              # :903-911 residual + norm, one pass
-        return x + self.mlp(h)
+        return self.mlp(h, residual=x)
 
     def decode(self, x, cos, sin, kcache, vcache, t, key_mask):
         x = x + self.self_attn.decode(self.input_layernorm(x), cos, sin, kcache, vcache, t, key_mask)
