@@ -30,7 +30,8 @@ def process_images(images: Sequence, image_processor: Sequence, model_cfg=None, 
     the reference's (float32 pixels rounded once to ``dtype``)."""
     device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     key = (tuple(id(p) for p in image_processor), str(device), dtype)
-    pre = _PREPROCESSORS.get(key)
-    if pre is None:
-        pre = _PREPROCESSORS[key] = GpuImagePreprocessor(image_processor, device, dtype)
-    return pre(images)
+    hit = _PREPROCESSORS.get(key)
+    if hit is None or any(a is not b for a, b in zip(hit[0], image_processor)):
+        # the entry keeps the processors alive, so their ids cannot be recycled for other objects while it exists
+        hit = _PREPROCESSORS[key] = (list(image_processor), GpuImagePreprocessor(image_processor, device, dtype))
+    return hit[1](images)
