@@ -12,6 +12,20 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 #define CMB_WAVE 64
 
+// 8 fp32 -> 8 bf16 with four v_cvt_pk_bf16_f32 (a scalar (bf16_t)x per element costs a convert + a permute each)
+__device__ __forceinline__ bf16x8_t cvt8_bf16(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                              float a7) {
+  typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+  typedef float f32x2_v __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+  const f32x2_v v0 = {a0, a1}, v1 = {a2, a3}, v2 = {a4, a5}, v3 = {a6, a7};
+  const u32x4_v w = {__builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2_v)),
+                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2_v)),
+                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_v)),
+                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v3, bf16x2_v))};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+
 #define CMB_CHECK_LAUNCH()                                   \
   do {                                                       \
     hipError_t e__ = hipGetLastError();                      \

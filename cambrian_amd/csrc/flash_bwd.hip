@@ -70,15 +70,7 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-// 8 fp32 -> 8 bf16 with four v_cvt_pk_bf16_f32 (a scalar (bf16_t)x per element costs a convert + a permute each)
-__device__ __forceinline__ bf16x8_t cvt8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
-  const f32x2_t v0 = {a0, a1}, v1 = {a2, a3}, v2 = {a4, a5}, v3 = {a6, a7};
-  const u32x4_t w = {__builtin_bit_cast(uint32_t, __builtin_convertvector(v0, bf16x2_t)),
-                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v1, bf16x2_t)),
-                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v2, bf16x2_t)),
-                     __builtin_bit_cast(uint32_t, __builtin_convertvector(v3, bf16x2_t))};
-  return __builtin_bit_cast(bf16x8_t, w);
-}
+#define cvt8 cvt8_bf16
 
 // A 64-row x 128 tile moves global -> registers -> LDS in two halves so that the global loads of the NEXT tile can be
 // in flight while the current one is being multiplied (tile_load after the barrier that publishes the current tile,

@@ -119,39 +119,47 @@ __global__ void __launch_bounds__(256) vit_attn_bf16_kernel(const bf16_t* __rest
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
       }
     }
+    // VALU budget (one pass per 32 MFMAs of the wave; see flash_bwd.hip): only the last tile can hold keys >= N, scores
+    // stay un-scaled until one fma feeds v_exp_f32, the accumulators are rescaled only when some lane's maximum moved,
+    // P is converted two elements per v_cvt_pk_bf16_f32.
+    if (t * 64 + 64 > N) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (key >= N) s[kt][r] = -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-        const float v = (key < N) ? s[kt][r] * scale_log2e : -INFINITY;
-        s[kt][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;   // scale > 0
     const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
+    if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+    }
     m = m_new;
-    l *= alpha;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(s[kt][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], scale_log2e, -m_new));
         l += pv;
         s[kt][r] = pv;
       }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int kt = kb >> 1, hh = kb & 1;
-      bf16x8_t pf;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)s[kt][8 * hh + e];
+      const bf16x8_t pf = cvt8_bf16(s[kt][8 * hh + 0], s[kt][8 * hh + 1], s[kt][8 * hh + 2], s[kt][8 * hh + 3],
+                                    s[kt][8 * hh + 4], s[kt][8 * hh + 5], s[kt][8 * hh + 6], s[kt][8 * hh + 7]);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const bf16_t* vrow = sV + (d * 32 + j) * LDV + kt * 32 + 16 * hh + 4 * g;
