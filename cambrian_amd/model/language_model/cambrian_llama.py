@@ -79,13 +79,61 @@ def _fused_frozen_weight(owner: nn.Module, key: str, mods) -> Optional[torch.Ten
     return cached[1]
 
 
+class FrozenLinearFn(torch.autograd.Function):
+    """y = x @ W^T (+ residual) for a FROZEN W [N,K], with the backward dX = g @ W computed as ``F.linear(g, W_t)`` on a
+    cached transposed copy W_t [K,N].  hipBLASLt is fastest when both operands are contiguous along the contraction
+    dimension (tools/mm_layout_probe.py: 1.34-1.64 PFLOP/s for that form against 1.36-1.41 for ``g @ W`` at the decoder's
+    shapes), which the forward already is; the copy gives the backward the same form (-12 % on every decoder dX GEMM) for
+    one more resident copy of the frozen weights (15 GB of the 288 GB for Llama-3-8B)."""
+
+    @staticmethod
+    def forward(ctx, x2, w, w_t, res2):
+        """2-D in, 2-D out (fresh tensor): callers reshape outside, so later in-place users of the result (the SVA hook's
+        scatter, the fused cross-entropy writing dlogits over the logits) never touch a view made inside a Function."""
+        ctx.save_for_backward(w_t)
+        ctx.has_res = res2 is not None
+        return F.linear(x2, w) if res2 is None else torch.addmm(res2, x2, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        (w_t,) = ctx.saved_tensors
+        dx = F.linear(g, w_t) if ctx.needs_input_grad[0] else None
+        return dx, None, None, (g if ctx.has_res else None)
+
+
+def _frozen_transposed(owner: nn.Module, key: str, w: torch.Tensor) -> torch.Tensor:
+    """W^T (contiguous) of a frozen weight, cached on ``owner`` and rebuilt when the weight moves or changes."""
+    tag = (w.data_ptr(), w._version, w.dtype)
+    cached = owner.__dict__.get(key)
+    if cached is None or cached[0] != tag:
+        cached = (tag, w.detach().t().contiguous())
+        owner.__dict__[key] = cached
+    return cached[1]
+
+
+def frozen_linear(owner: nn.Module, key: str, x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None):
+    """``F.linear(x, w)`` (+ residual); frozen bias-free GPU weights take FrozenLinearFn, anything else the stock path."""
+    if w.requires_grad or not x.is_cuda:
+        y = F.linear(x, w)
+        return y if residual is None else residual + y
+    x2 = x.reshape(-1, x.shape[-1])
+    res2 = None if residual is None else residual.reshape(-1, w.shape[0])
+    y = FrozenLinearFn.apply(x2, w, _frozen_transposed(owner, key, w), res2)
+    return y.view(*x.shape[:-1], w.shape[0])
+
+
+def _lin(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """nn.Linear forward; frozen bias-free weights go through FrozenLinearFn (faster dX)."""
+    if lin.bias is not None:
+        return lin(x)
+    return frozen_linear(lin, "_w_t", x, lin.weight)
+
+
 def _down_proj(lin: nn.Linear, inner: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
-    if residual is None:
-        return lin(inner)
-    if lin.bias is not None or not residual.is_contiguous():
-        return residual + lin(inner)
-    H = residual.shape[-1]
-    return torch.addmm(residual.view(-1, H), inner.reshape(-1, inner.shape[-1]), lin.weight.t()).view_as(residual)
+    if lin.bias is not None:
+        y = lin(inner)
+        return y if residual is None else residual + y
+    return frozen_linear(lin, "_w_t", inner, lin.weight, residual)   # skip connection inside the GEMM (C = residual)
 
 
 class LlamaMLP(nn.Module):
@@ -101,7 +149,7 @@ class LlamaMLP(nn.Module):
         instead of a separate elementwise pass over [tokens, hidden]."""
         w_gu = _fused_frozen_weight(self, "_w_gate_up", (self.gate_proj, self.up_proj))
         if w_gu is not None and x.is_cuda:
-            inner = ops.swiglu_packed(F.linear(x, w_gu))
+            inner = ops.swiglu_packed(frozen_linear(self, "_w_gate_up_t", x, w_gu))
         else:
             inner = ops.swiglu(self.gate_proj(x), self.up_proj(x))
         return _down_proj(self.down_proj, inner, residual)
@@ -123,7 +171,7 @@ class LlamaAttention(nn.Module):
         B, S, _ = x.shape
         w_qkv = _fused_frozen_weight(self, "_w_qkv", (self.q_proj, self.k_proj, self.v_proj))
         if w_qkv is not None and x.is_cuda:
-            q, k, v = ops.qkv_rope(F.linear(x, w_qkv), cos, sin, self.nh, self.nkv, self.hd)
+            q, k, v = ops.qkv_rope(frozen_linear(self, "_w_qkv_t", x, w_qkv), cos, sin, self.nh, self.nkv, self.hd)
             if kv_out is not None:
                 kv_out.append((k, v))
             if attn_mask is None and torch.is_grad_enabled() and q.requires_grad and ops.causal_attention_supported(q, k):
@@ -131,7 +179,7 @@ class LlamaAttention(nn.Module):
             else:
                 o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                                    enable_gqa=self.nkv != self.nh)
-            return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
+            return _lin(self.o_proj, o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
         q = ops.rope(self.q_proj(x).view(B * S, self.nh, self.hd), cos, sin).view(B, S, self.nh, self.hd).transpose(1, 2)
         k = ops.rope(self.k_proj(x).view(B * S, self.nkv, self.hd), cos, sin).view(B, S, self.nkv, self.hd).transpose(1, 2)
         v = self.v_proj(x).view(B, S, self.nkv, self.hd).transpose(1, 2)
@@ -334,7 +382,7 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
             # one context row per query — consumed by the general per-sample hook (cambrian_llama.py:209-253)
             sva = SvaDynamic(sva, _masks, _final_size, _ctx)
         hidden = self.model(inputs_embeds.to(self.model.llm_dtype), position_ids, attention_mask, sva)
-        logits = self.lm_head(hidden)                                                # :402-408
+        logits = _lin(self.lm_head, hidden)                                          # :402-408
         loss = None
         if labels is not None and getattr(self.config, "fused_loss", False):
             # :409-422 without logits.float() / the shifted copy: labels are shifted instead of the logits (position

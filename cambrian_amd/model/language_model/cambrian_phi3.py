@@ -32,7 +32,7 @@ except Exception:  # pragma: no cover
 
 from ... import lib as L
 from ... import ops
-from .cambrian_llama import CambrianLlamaForCausalLM, CambrianLlamaModel, HipRMSNorm, _down_proj
+from .cambrian_llama import CambrianLlamaForCausalLM, CambrianLlamaModel, HipRMSNorm, _down_proj, _lin
 
 
 class CambrianConfig(Phi3Config):
@@ -61,7 +61,7 @@ class Phi3MLP(nn.Module):
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, **kw)
 
     def forward(self, x, residual=None):
-        inner = ops.swiglu_packed(self.gate_up_proj(x))                          # up * silu(gate), :303-308
+        inner = ops.swiglu_packed(_lin(self.gate_up_proj, x))                    # up * silu(gate), :303-308
         return _down_proj(self.down_proj, inner, residual)                       # skip connection folded into the GEMM
 
 
@@ -76,7 +76,7 @@ class Phi3Attention(nn.Module):
 
     def forward(self, x, cos, sin, attn_mask, kv_out: Optional[list] = None):
         B, S, _ = x.shape
-        q, k, v = ops.qkv_rope(self.qkv_proj(x).contiguous(), cos, sin, self.nh, self.nkv, self.hd)
+        q, k, v = ops.qkv_rope(_lin(self.qkv_proj, x).contiguous(), cos, sin, self.nh, self.nkv, self.hd)
         if kv_out is not None:
             kv_out.append((k, v))
         if attn_mask is None and torch.is_grad_enabled() and q.requires_grad and ops.causal_attention_supported(q, k):
@@ -84,7 +84,7 @@ class Phi3Attention(nn.Module):
         else:
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                                enable_gqa=self.nkv != self.nh)
-        return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
+        return _lin(self.o_proj, o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
 
     def decode(self, x, cos, sin, kcache, vcache, t: int, key_mask):
         """One new token per sequence against the cache (see LlamaAttention.decode)."""
