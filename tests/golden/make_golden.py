@@ -663,6 +663,35 @@ def golden_config0():
     print("config0_small.pt written; arch dparams:", sorted(fx["arch"]["dparams"].keys()))
 
 
+def golden_sampler():
+    """get_length_grouped_indices / get_modality_length_grouped_indices / split_to_even_chunks of
+    cambrian/train/cambrian_trainer.py (lines 69-130 exec'd: the module itself imports torch_xla / gcsfs)."""
+    src = open(f"{REF}/cambrian/train/cambrian_trainer.py").read().split("\n")
+    ns = {"torch": torch}
+    exec("\n".join(src[68:130]), ns)
+    cases = []
+    g = torch.Generator().manual_seed(5)
+    for n, bs, ws, mixed in [(64, 4, 2, False), (100, 4, 8, False), (37, 2, 4, False), (96, 4, 2, True), (203, 8, 4, True),
+                             (50, 2, 8, True), (16, 4, 4, False)]:
+        lengths = torch.randint(1, 2000, (n,), generator=g).tolist()
+        if mixed:
+            sign = torch.randint(0, 3, (n,), generator=g).tolist()
+            lengths = [l if s else -l for l, s in zip(lengths, sign)]
+        torch.manual_seed(1000 + n)          # the per-modality grouping draws from the GLOBAL generator
+        gen = torch.Generator().manual_seed(n * 7 + bs)
+        fn = ns["get_modality_length_grouped_indices"] if mixed else ns["get_length_grouped_indices"]
+        out = fn(lengths, bs, ws, generator=gen)
+        cases.append(dict(lengths=lengths, batch_size=bs, world_size=ws, mixed=mixed, global_seed=1000 + n,
+                          gen_seed=n * 7 + bs, indices=list(out)))
+    chunks = []
+    for n, k in [(12, 4), (13, 4), (8, 8), (30, 3)]:
+        lengths = torch.randint(1, 50, (n,), generator=g).tolist()
+        idx = sorted(range(n), key=lambda i: lengths[i], reverse=True)
+        chunks.append(dict(indices=idx, lengths=lengths, k=k, out=ns["split_to_even_chunks"](idx, lengths, k)))
+    torch.save(dict(cases=cases, chunks=chunks), f"{OUT}/sampler_cases.pt")
+    print("sampler_cases.pt written:", len(cases), "cases")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sva"]
     for w in which:
