@@ -118,7 +118,10 @@ def frozen_linear(owner: nn.Module, key: str, x: torch.Tensor, w: torch.Tensor, 
         return y if residual is None else residual + y
     x2 = x.reshape(-1, x.shape[-1])
     res2 = None if residual is None else residual.reshape(-1, w.shape[0])
-    y = FrozenLinearFn.apply(x2, w, _frozen_transposed(owner, key, w), res2)
+    if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
+        y = FrozenLinearFn.apply(x2, w, _frozen_transposed(owner, key, w), res2)
+    else:   # eval / generate: nothing will be back-propagated, so no transposed copy is made or kept
+        y = F.linear(x2, w) if res2 is None else torch.addmm(res2, x2, w.t())
     return y.view(*x.shape[:-1], w.shape[0])
 
 
