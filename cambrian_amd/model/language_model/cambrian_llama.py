@@ -363,6 +363,36 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
     def device(self):
         return self.lm_head.weight.device
 
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def resize_token_embeddings(self, new_num_tokens: int):
+        """HF ``PreTrainedModel.resize_token_embeddings`` for the two vocabulary-sized matrices (``load_pretrained_model``
+        calls it after adding the image tokens, model/builder.py:158): old rows kept, new rows ~ N(0, initializer_range)."""
+        old = self.model.embed_tokens.weight
+        n_old, H = old.shape
+        if new_num_tokens == n_old:
+            return self.model.embed_tokens
+        std = float(getattr(self.config, "initializer_range", 0.02))
+
+        def grown(w):
+            out = torch.empty((new_num_tokens, H), dtype=w.dtype, device=w.device).normal_(0.0, std)
+            n = min(n_old, new_num_tokens)
+            out[:n] = w.detach()[:n]
+            return out
+
+        emb = nn.Embedding(new_num_tokens, H, device=old.device, dtype=old.dtype)
+        emb.weight = nn.Parameter(grown(old), requires_grad=old.requires_grad)
+        self.model.embed_tokens = emb
+        head = nn.Linear(H, new_num_tokens, bias=False, device=old.device, dtype=self.lm_head.weight.dtype)
+        head.weight = nn.Parameter(grown(self.lm_head.weight), requires_grad=self.lm_head.weight.requires_grad)
+        self.lm_head = head
+        self.vocab_size = self.config.vocab_size = new_num_tokens
+        return self.model.embed_tokens
+
     def forward(self, *args, **kwargs):
         """``config.fp8_projections`` (BASELINE configs[4]): the forward GEMMs of the SVA-side projections — aux
         projectors, connector and in-LLM SVA layers, mm_projector, i.e. everything that goes through ``ops.linear`` —
