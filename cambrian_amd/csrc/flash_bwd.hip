@@ -16,7 +16,7 @@
 // Layout: all of q, k, v, o, do, dq, dk, dv are addressed as [B, S, H, 128] through (batch, token, head) element strides
 // (token-major storage, what ops.qkv_rope produces and the attention returns); lse / D are fp32 [B, H, S].
 #include "common.h"
-#include "gemm_layout.h"
+#include "flash_map.h"
 
 namespace {
 
@@ -38,33 +38,6 @@ struct FlashParams {
   int kv_len;   // non-causal kernels: keys >= kv_len are padding (masked); S is kv_len rounded up to 128
   float scale;
 };
-
-// Block -> work mapping.  The hardware deals linear block ids round-robin to the 8 XCDs; with a (query block, head,
-// batch) grid every XCD would get two fixed query blocks of each head — under the causal mask XCD 0 then carries 2.4x
-// the tiles of XCD 7.  Instead the grid is 1-D and an XCD owns a contiguous range of (batch, KV head) groups: all query
-// blocks (heavy and light) and all query heads of a group run on one XCD, which balances the causal triangle and keeps
-// the group's K / V in that XCD's L2.  Within a group the heaviest blocks come first.
-struct FlashBlock {
-  int b, hk, h, blk;
-};
-__device__ __forceinline__ FlashBlock flash_block_qh(const int nqb, const int H, const int HKV) {  // nqb work items per head
-  const int group = H / HKV, per = nqb * group;
-  const int id = gl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int gi = id / per, w = id - gi * per;
-  FlashBlock f;
-  f.b = gi / HKV; f.hk = gi - f.b * HKV;
-  f.blk = w / group;
-  f.h = f.hk * group + w % group;
-  return f;
-}
-__device__ __forceinline__ FlashBlock flash_block_kv(const int per, const int HKV) {  // `per` work items per (batch, KV head)
-  const int id = gl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
-  const int gi = id / per;
-  FlashBlock f;
-  f.b = gi / HKV; f.hk = gi - f.b * HKV; f.h = 0;
-  f.blk = id - gi * per;
-  return f;
-}
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -136,11 +109,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
   // Causal: query block qb walks (qb + 1) * 2 key tiles, so a workgroup takes the PAIR (i, nqb-1-i) one after the
   // other — uniform work per workgroup, no tail.
   const int nqb = p.S / 128;
-  const FlashBlock fb = flash_block_qh(CAUSAL ? (nqb + 1) / 2 : nqb, p.H, p.HKV);
+  const FlashBlock fb = flash_block_qh((int)blockIdx.x, (int)gridDim.x, flash_items(nqb, CAUSAL), p.H, p.HKV);
   const int b = fb.b, h = fb.h, hk = fb.hk;
-  const int nrep = (CAUSAL && fb.blk != nqb - 1 - fb.blk) ? 2 : 1;
+  const int nrep = flash_pair_count(nqb, fb.blk, CAUSAL);
   for (int rep = 0; rep < nrep; ++rep) {
-  const int qb = rep == 0 ? nqb - 1 - fb.blk : fb.blk;
+  const int qb = flash_pair_q(nqb, fb.blk, rep, CAUSAL);
   const int q0 = qb * 128 + wave * 32;
   const int qi = q0 + j;
   const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
@@ -262,11 +235,11 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
   const int nqb = p.S / 128;   // causal: pairs (i, nqb-1-i), as in the forward
-  const FlashBlock fb = flash_block_qh(CAUSAL ? (nqb + 1) / 2 : nqb, p.H, p.HKV);
+  const FlashBlock fb = flash_block_qh((int)blockIdx.x, (int)gridDim.x, flash_items(nqb, CAUSAL), p.H, p.HKV);
   const int b = fb.b, h = fb.h, hk = fb.hk;
-  const int nrep = (CAUSAL && fb.blk != nqb - 1 - fb.blk) ? 2 : 1;
+  const int nrep = flash_pair_count(nqb, fb.blk, CAUSAL);
   for (int rep = 0; rep < nrep; ++rep) {
-  const int qb = rep == 0 ? nqb - 1 - fb.blk : fb.blk;
+  const int qb = flash_pair_q(nqb, fb.blk, rep, CAUSAL);
   const int q0 = qb * 128 + wave * 32;
   const int qi = q0 + j;                                  // this lane's query (S % 128 == 0: always valid)
   const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
@@ -394,11 +367,11 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   // Causal: key block kb meets (nkb - kb) * 2 query tiles per head, so a workgroup takes the PAIR (i, nkb-1-i) one
   // after the other — every workgroup does the same amount of work and the grid has no tail.
   const int nkb = p.S / 128;
-  const FlashBlock fb = flash_block_kv(CAUSAL ? (nkb + 1) / 2 : nkb, p.HKV);
+  const FlashBlock fb = flash_block_kv((int)blockIdx.x, (int)gridDim.x, flash_items(nkb, CAUSAL), p.HKV);
   const int b = fb.b, hk = fb.hk;
-  const int nrep = (CAUSAL && fb.blk != nkb - 1 - fb.blk) ? 2 : 1;
+  const int nrep = flash_pair_count(nkb, fb.blk, CAUSAL);
   for (int rep = 0; rep < nrep; ++rep) {
-  const int kb = rep == 0 ? fb.blk : nkb - 1 - fb.blk;
+  const int kb = flash_pair_k(nkb, fb.blk, rep, CAUSAL);
   const int k0 = kb * 128 + wave * 32;
   const int ki = k0 + j;
   const int group = p.H / p.HKV;
@@ -568,7 +541,8 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
   hipStream_t s = (hipStream_t)stream;
   const int64_t nkb = S / 128;
-  const dim3 gq((unsigned)((causal ? (nkb + 1) / 2 : nkb) * H * B)), gk((unsigned)((causal ? (nkb + 1) / 2 : nkb) * HKV * B));   // 1-D: see flash_block_*
+  const int items = flash_items((int)nkb, causal != 0);
+  const dim3 gq((unsigned)((int64_t)items * H * B)), gk((unsigned)((int64_t)items * HKV * B));   // 1-D: flash_map.h
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
@@ -605,7 +579,7 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
   const int64_t nqb = S / 128;
-  const dim3 grid((unsigned)((causal ? (nqb + 1) / 2 : nqb) * H * B));   // 1-D: see flash_block_qh
+  const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal != 0) * H * B));   // 1-D: flash_map.h
   if (causal)
     hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
   else
