@@ -76,3 +76,46 @@ def test_gradsync_single_process_is_identity():
     m2(x).sum().backward()
     for a, b in zip(m.parameters(), m2.parameters()):
         assert torch.equal(a.grad, b.grad)
+
+
+def _worker_sampler(rank, world, port, q):
+    """The whole N > 1 recipe on CPU: LengthGroupedSampler order -> rank_batches cut -> per-rank step -> GradSync.  The
+    averaged gradient must equal the single-process gradient of the mean loss over the whole megabatch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cambrian_amd.train.dp import GradSync, init_distributed
+    from cambrian_amd.train.sampler import LengthGroupedSampler, rank_batches
+    init_distributed("gloo")
+    n, bs = 32, 4
+    data = torch.randn(n, 16, generator=torch.Generator().manual_seed(3))
+    lengths = torch.randint(1, 100, (n,), generator=torch.Generator().manual_seed(4)).tolist()
+    order = list(LengthGroupedSampler(bs, world, lengths=lengths, generator=torch.Generator().manual_seed(5)))
+    mine = rank_batches(order, rank, world, bs)
+    m = _model()
+    sync = GradSync(list(m.parameters()), bucket_mb=0.01)
+    ok = True
+    for step, idx in enumerate(mine):
+        for p in m.parameters():
+            p.grad = None
+        m(data[idx]).pow(2).mean().backward()
+        sync.finish()
+        ref = _model()
+        mega = order[step * world * bs:(step + 1) * world * bs]
+        ref(data[mega]).pow(2).mean().backward()      # equal per-rank batch sizes: mean of means == mean over the megabatch
+        ok &= all(torch.allclose(a.grad, b.grad, atol=1e-6, rtol=1e-5) for a, b in zip(m.parameters(), ref.parameters()))
+    q.put((rank, ok, len(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sampler_cut_plus_gradsync_equals_megabatch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sampler, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, 4), (1, True, 4)]
