@@ -242,7 +242,7 @@ static int tile_override() {
 }
 static bool use_tile256(int M, int N, int splits, int hint) {
   const int ov = hint ? hint : tile_override();
-  if (ov == 256 || ov == 2560 || ov == 2561) return true;
+  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2574) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -250,6 +250,22 @@ static bool use_tile256(int M, int N, int splits, int hint) {
   const long rem = t128 % 512;
   const double c128 = 0.667 * ((double)(t128 / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.6 : 1.0)));
   return c256 <= c128;
+}
+
+// The 256 x 256 kernels address a tile's rows as a wave-uniform 64-bit base + a 32-bit per-lane byte offset: the span of
+// 256 consecutive (row-mapped) rows of A and of B must fit (upper bound; negative strides never qualify).
+static bool tile_span_fits_u32(const RowMap& m, int64_t ldb) {
+  if (m.s0 < 0 || m.s1 < 0 || m.s2 < 0 || ldb < 0) return false;
+  double span = 256.0 * (double)m.s2;
+  if (m.n1) span += (256.0 / (double)m.n2 + 1.0) * (double)m.s1 + (256.0 / (double)m.n1 + 1.0) * (double)m.s0;
+  return 2.0 * span + 256.0 < 4.0e9 && 2.0 * 256.0 * (double)ldb + 256.0 < 4.0e9;
+}
+
+// gemm_p4.hip walks 32-deep stages NS ahead across tile boundaries: every item (tile x K slice) must be at least NS
+// stages long.
+static bool p4_ok(const GemmParams& p, int splits, int ns) {
+  const int last = p.K - (splits - 1) * p.k_per_split;
+  return last / 32 >= ns && p.k_per_split / 32 >= ns;
 }
 
 template <typename T>
@@ -295,7 +311,16 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   }
   int rc;
   if constexpr (sizeof(T) == 2) {
-    rc = use_tile256(p.M, p.N, splits, d->tile_hint) ? launch_gemm256_bf16(p, splits, d->tile_hint == 2561 ? 1 : 0, s) : launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+    // tile_hint / CMB_GEMM_TILE: 128 | 256 (auto kernel) | 2560 / 2561 (8-wave kernel, schedule 0 / 1) | 2570 / 2574
+    // (persistent 4-wave kernel, ring of 5 / 4 stages)
+    const int ov = d->tile_hint ? d->tile_hint : tile_override();
+    const int ns = (ov == 2574) ? 4 : 5;
+    if (!use_tile256(p.M, p.N, splits, d->tile_hint) || !tile_span_fits_u32(p.a_map, p.ldb))
+      rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+    else if (ov == 2560 || ov == 2561 || !p4_ok(p, splits, ns))
+      rc = launch_gemm256_bf16(p, splits, ov == 2561 ? 1 : 0, s);
+    else
+      rc = launch_gemm_p4_bf16(p, splits, ns, s);
   } else {
     rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   }

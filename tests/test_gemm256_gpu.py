@@ -1,4 +1,5 @@
-"""GPU parity + race screen of the 256x256 / 8-phase GEMM configuration (cambrian_amd/csrc/gemm256.hip).
+"""GPU parity + race screen of the 256x256 GEMM configurations: the 8-wave / 8-phase kernel (cambrian_amd/csrc/gemm256.hip)
+and the persistent 4-wave kernel (cambrian_amd/csrc/gemm_p4.hip; K < 160 falls back to the former inside the library).
 
 Reference = fp32 matmul of the SAME bf16-rounded operands (so the only difference is the accumulation order);
 the 128x128 configuration of the same library is the second, independent check (bf16 outputs must agree to one
@@ -19,10 +20,13 @@ def _ops():
 
 
 SHAPES = [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 512, 256), (300, 264, 320), (1000, 2048, 1024),
-          (4616, 1024, 1024), (257, 8, 64), (33, 520, 128), (2048, 2048, 2048), (8 * 730, 1536, 1536)]
+          (4616, 1024, 1024), (257, 8, 64), (33, 520, 128), (2048, 2048, 2048), (8 * 730, 1536, 1536),
+          (4352, 6400, 192), (8192, 8448, 320), (65536, 1536, 384)]   # > 256 tiles: several persistent rounds per CU
 
 
-SCHEDS = [2560, 2561]  # tile_hint: 256x256 tile, schedule 0 (8-phase ping-pong) / 1 (in-wave pipeline, 1 barrier per K-tile)
+# tile_hint: 256x256 tile; 2560 / 2561 = 8-wave kernel, schedule 0 (8-phase ping-pong) / 1 (in-wave pipeline, 1 barrier
+# per K-tile); 2570 / 2574 = persistent 4-wave kernel with an LDS ring of 5 / 4 stages
+SCHEDS = [2560, 2561, 2570, 2574]
 
 
 @pytest.mark.parametrize("tile", SCHEDS)
@@ -47,7 +51,7 @@ def test_gemm256_race_screen(dev, tile):
     bit-identical, across many repetitions and while other work loads the chip."""
     ops, L = _ops()
     g = torch.Generator().manual_seed(3)
-    for M, N, K in [(4096, 4096, 4096), (8 * 10944, 2048, 1024), (1024, 1024, 8192)]:
+    for M, N, K in [(4096, 4096, 4096), (8 * 10944, 2048, 1024), (1024, 1024, 8192), (16 * 4096, 6144, 1536)]:
         a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
         w = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
         first = ops.k_gemm(a, w, tile=tile)
