@@ -242,7 +242,7 @@ static int tile_override() {
 }
 static bool use_tile256(int M, int N, int splits, int hint) {
   const int ov = hint ? hint : tile_override();
-  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2574) return true;
+  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2574 || (ov >= 2600 && ov < 2856)) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -314,13 +314,13 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
     // tile_hint / CMB_GEMM_TILE: 128 | 256 (auto kernel) | 2560 / 2561 (8-wave kernel, schedule 0 / 1) | 2570 / 2574
     // (persistent 4-wave kernel, ring of 5 / 4 stages)
     const int ov = d->tile_hint ? d->tile_hint : tile_override();
-    const int ns = (ov == 2574) ? 4 : 5;
+    const int ns = 5;
     if (!use_tile256(p.M, p.N, splits, d->tile_hint) || !tile_span_fits_u32(p.a_map, p.ldb))
       rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
     else if (ov == 2560 || ov == 2561 || !p4_ok(p, splits, ns))
       rc = launch_gemm256_bf16(p, splits, ov == 2561 ? 1 : 0, s);
     else
-      rc = launch_gemm_p4_bf16(p, splits, ns, s);
+      rc = launch_gemm_p4_bf16(p, splits, ns, (ov >= 2600 && ov < 2856) ? ov - 2600 : 0, s);
   } else {
     rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   }

@@ -156,6 +156,6 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
 int launch_gemm256_bf16(GemmParams& p, int splits, int sched, hipStream_t s);
 
 // gemm_p4.hip: persistent 256x256 bf16 tile, 4 waves x (128 x 128), LDS ring of `ns` (4 or 5) 32-deep stages.
-int launch_gemm_p4_bf16(GemmParams& p, int splits, int ns, hipStream_t s);
+int launch_gemm_p4_bf16(GemmParams& p, int splits, int ns, int var, hipStream_t s);
 
 }  // namespace cmb_gemm_detail

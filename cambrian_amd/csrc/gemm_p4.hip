@@ -8,26 +8,33 @@
 //     registers, 16 KB of fragments per wave per 64-deep K-step (2/3 of the LDS traffic per MFMA), 32 MFMAs between
 //     barriers, the other waves' instructions never contend for the SIMD;
 //   * the LDS is a ring of NS stages of 32 k-values (A: 256 rows x 64 B, B: 256 rows x 64 B = 32 KiB per stage) filled
-//     by LDS-DMA (global_load_lds_dwordx4) NS stages ahead with a counted vmcnt; ONE barrier per stage;
+//     by LDS-DMA (global_load_lds_dwordx4) NS - 2 stages ahead with a counted vmcnt; ONE barrier per stage;
 //   * the workgroup is PERSISTENT (grid = number of CUs): the DMA cursor runs ahead across tile boundaries, so the
-//     next tile's first NS stages are in flight / landed while the current tile's epilogue runs, and the epilogue
+//     next tile's first stages are in flight / landed while the current tile's epilogue runs, and the epilogue
 //     leaves straight from the accumulators (v_permlane32_swap pairs two half-waves' column groups into 8 consecutive
 //     columns: 16-byte bf16 stores, no LDS round trip, no barrier), its stores draining under the next tile's MFMAs.
 //
-// In-wave software pipeline of one stage g (stage slot g % NS; fragments of the two 16-deep sub-steps ks = 0, 1 live
-// in register sets 0 / 1):
-//     phase A:  16 MFMA on set 0   |  8 ds_read_b128 of (g, ks = 1) -> set 1   (interleaved with the first 8 MFMAs)
-//               s_waitcnt lgkmcnt(0)            this wave's last reads of slot g % NS have returned
-//               s_waitcnt vmcnt(8 (NS - 2))     this wave's DMA pieces of stage g + 1 have landed
-//               s_barrier                       => stage g + 1 is visible to every wave, slot g % NS is free
-//     phase B:  16 MFMA on set 1   |  8 ds_read_b128 of (g + 1, ks = 0) -> set 0  |  8 LDS-DMA of stage g + NS -> slot g % NS
-//               s_waitcnt lgkmcnt(0)
-// RAW: the DMA of stage g + 1 was issued NS - 1 iterations earlier; the counted wait leaves exactly the NS - 2 younger
-//      stages (8 instructions per wave each) in flight, precedes the barrier, and the first read of stage g + 1 follows
-//      the barrier.  WAR: slot g % NS is re-filled only after the barrier that every wave reaches with its reads of
-//      that slot retired (lgkmcnt(0)).  Global stores of an epilogue also count on vmcnt: they are younger than the
-//      stage being waited for, so the counted wait can only wait longer, never shorter (memory operations of a wave
-//      retire in order on gfx9).
+// One wave per SIMD means every cycle an LDS / vector-memory instruction spends waiting to be ACCEPTED is a cycle the
+// matrix pipe idles.  Measured (tools/gemm_lab.py, 8192^3): the MFMA stream alone runs 2.04 PFLOP/s; with the four
+// waves issuing their 16 ds_read_b128 per stage in the same cycles it drops to 1.57, with their 8 LDS-DMA pieces to
+// 1.30 — 19 / 74 cycles per instruction, i.e. the four waves queueing on the CU's one LDS and one address unit.  The
+// schedule therefore STAGGERS the waves: wave w issues its reads (in pairs) after MFMA t with t % 4 == w and its DMA
+// pieces after MFMA t with t % 4 == (w + 2) % 4, so in every 32-cycle MFMA slot one wave reads, one wave stages, two
+// only multiply.  The stage body is instantiated per wave (template parameter W) and selected once per tile.
+//
+// Stage g (ring slot g % NS; fragments of the two 16-deep sub-steps ks = 0, 1 live in register sets 0 / 1):
+//     phase A:  16 MFMA on set 0 | reads of (g, ks 1) -> set 1   | DMA pieces 4..7 of stage g + NS - 2 -> slot (g - 2) % NS
+//               s_waitcnt vmcnt(8 (NS - 3))     this wave's pieces of stage g + 1 have landed
+//               s_barrier                       => stage g + 1 is visible to every wave
+//     phase B:  16 MFMA on set 1 | reads of (g + 1, ks 0) -> set 0 | DMA pieces 0..3 of stage g + NS - 1 -> slot (g - 1) % NS
+// RAW: stage g + 1 was issued in phase B (g + 2 - NS) / phase A (g + 3 - NS); at the wait the NS - 3 younger stages
+//      (8 pieces per wave each) are all that may still be in flight; the wait precedes the barrier and the first read
+//      of stage g + 1 follows it.  WAR: slot (g - 1) % NS is refilled after barrier g; its last reads (ks 1 of stage
+//      g - 1) were issued in phase A (g - 1) and each feeds an MFMA of phase B (g - 1), so every wave has retired them
+//      (the compiler's own counted lgkmcnt in front of those MFMAs) before it reaches barrier g.  No lgkmcnt(0)
+//      drain is needed anywhere.  Global stores of an epilogue also count on vmcnt: they are younger than the stage
+//      being waited for, so the counted wait can only wait longer, never shorter (a wave's memory operations retire
+//      in order on gfx9).
 //
 // LDS stage layout (gemm_layout.h documents the 128-byte-row variant): rows of 64 B = 4 chunks of 16 B; chunk c of row
 // r lives at r*64 + ((c ^ ((r >> 2) & 3)) << 4).  ds_read_b128 is serviced in 16-lane groups over a 256-byte bank row
@@ -47,14 +54,32 @@ constexpr int kP4Pieces = 8;                 // LDS-DMA instructions per wave pe
 #define P4_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // One LDS-DMA piece: 64 lanes x 16 B, wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset -> LDS bytes
-// [lds_addr + 16*lane, +16).  M0 is written and used in one statement (cdna_hip_programming.md §5.7).
-__device__ __forceinline__ void p4_glds(const char* sbase, uint32_t voff, uint32_t lds_addr) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 2\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_addr)
-      : "memory");
+// [lds_base + OFF + 16*lane, +16).  M0 (the LDS destination) is written and used in one statement and not restored:
+// nothing else in this kernel reads M0 (gfx9 DS instructions do not), which keeps a piece at 3 issue slots — with one
+// wave per SIMD every slot beyond ~7 per MFMA is matrix-pipe idle time (5 slots measured 42 cycles per piece).
+// A base that came out of v_readfirstlane needs 5 wait states before a VMEM instruction reads it: the callers'
+// SALU arithmetic on the base after every hand-over provides them.
+template <int OFF>
+__device__ __forceinline__ void p4_glds(const char* sbase, uint32_t voff, uint32_t lds_base) {
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_base), "n"(OFF)
+               : "memory", "m0", "scc");
+}
+
+// 16 consecutive floats at a wave-uniform address (scalar loads: they count on lgkmcnt, so unlike a vector load they
+// do not have to wait behind the tile's stores and LDS-DMA on vmcnt) -> this lane's 8: lanes 0-31 take floats 0..7,
+// lanes 32-63 floats 8..15 (the column halves of one 16-column group after the permlane32 swap).
+typedef float f32x16s_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void p4_colvec(const float* base, bool upper, float (&v)[8]) {
+  f32x16s_t o;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(o) : "s"(base) : "memory");
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float lo = o[e], hi = o[8 + e];
+    asm volatile("" : "+s"(lo), "+s"(hi));  // keep two scalars: select-of-extract otherwise becomes a dynamic extract
+    v[e] = upper ? hi : lo;
+  }
 }
 
 __device__ __forceinline__ const char* p4_uniform_ptr(const char* q) {
@@ -91,8 +116,20 @@ struct P4Src {
   int nk;
 };
 
-template <int ACT, int NS>
+// order in which a phase reads the NEXT phase's fragments (0..3 = A row block i, 4..7 = B column block j): the MFMA
+// order is (i, j) = (t >> 2, t & 3), so B0, A0 are needed first and A3 only by the 13th MFMA
+__host__ __device__ constexpr int p4_read_order(int n) {
+  return n == 0 ? 4 : n == 1 ? 0 : n == 2 ? 5 : n == 3 ? 6 : n == 4 ? 7 : n - 4;
+}
+
+// VAR: ablation bits (tools/gemm_lab.py, built with -DCMB_GEMM_LAB; all but 4 compute garbage — timing only):
+// 1 = no in-loop DMA, 2 = no in-loop fragment reads, 4 = no stagger (every wave runs wave 0's schedule), 8 = no barrier.
+template <int ACT, int NS, int VAR>
 __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, const int n_items) {
+  constexpr bool kNoDma = VAR & 1, kNoRead = VAR & 2, kNoBar = VAR & 8;
+  constexpr bool kPlainLoad = VAR & 16, kDummyWrite = VAR & 32;  // issue-cost probes (garbage results)
+  constexpr bool kBufLds = VAR & 64, kBufVgpr = VAR & 128;         // buffer_load forms of the piece (timing probes)
+  static_assert(NS >= 4, "the ring needs the stage being read, the next one and two being filled");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16x8_t frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -128,30 +165,79 @@ __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, con
     r.nk = it.nk;
     return r;
   };
-  // The cursor (cur) walks the workgroup's items NS stages ahead of the MFMAs; nxt describes the item after the
-  // cursor's.  The hand-over cur <- nxt at the end of an item is a register select (no branch inside the stage
-  // loop); nxt is refreshed once per tile, next to the epilogue.  Past the last item the cursor re-reads it: those
-  // stages land in ring slots nobody reads any more and are drained before the workgroup ends.
+  // The cursor (cur) walks the workgroup's items ahead of the MFMAs; nxt describes the item after the cursor's.  The
+  // hand-over cur <- nxt at the end of an item is a register select (no branch inside the stage loop); nxt is
+  // refreshed once per tile, next to the epilogue.  Past the last item the cursor re-reads it: those stages land in
+  // ring slots nobody reads any more and are drained before the workgroup ends.
   P4Src cur = src_of(first_item);
   P4Src nxt = src_of(first_item + stride <= last_item ? first_item + stride : last_item);
-  int d_k = 0;
-  auto dma_piece = [&](int slot, int pc) {
-    const uint32_t dst = dma_lds + (uint32_t)slot * (uint32_t)kP4Stage;
-    if (pc < 4) p4_glds(cur.a_base, cur.a_off[pc], dst + (uint32_t)pc * 1024u);
-    else p4_glds(cur.b_base, cur.b_off[pc - 4], dst + (uint32_t)kP4StageA + (uint32_t)(pc - 4) * 1024u);
+  // The A-row pieces (0..3) of a stage go out in one phase, its B-row pieces (4..7) in the next: the two halves of
+  // the cursor advance separately (each right after its own last piece), with their own stage counters.
+  int ka = 0, kb = 0, nka = cur.nk, nkb = cur.nk;
+  asm volatile("s_nop 4" ::: "memory");  // v_readfirstlane -> SGPR base -> first LDS-DMA: 5 wait states
+  // M0 <- LDS destination of piece pc in the ring slot whose first byte (for this wave) is `slot_lds`; issued one
+  // MFMA slot ahead of the piece itself (SALU write of M0 -> LDS-DMA needs a wait state; an s_nop in the same slot as
+  // the DMA is a slot the matrix pipe does not get)
+  auto dma_m0 = [&](uint32_t slot_lds, auto pc_c) {
+    constexpr int pc = decltype(pc_c)::value;
+    constexpr int off = pc < 4 ? pc * 1024 : kP4StageA + (pc - 4) * 1024;
+    if constexpr (!kPlainLoad) asm volatile("s_add_u32 m0, %0, %1" ::"s"(slot_lds), "n"(off) : "m0", "scc");
   };
-  auto dma_advance = [&]() {
-    ++d_k;
-    const bool sw = (d_k == cur.nk);
-    cur.a_base = sw ? nxt.a_base : cur.a_base + 64;
-    cur.b_base = sw ? nxt.b_base : cur.b_base + 64;
+  f32x4_t probe_buf[8];  // probes only: a "+v" chain pins each load's destination to one register for the whole kernel
+  if constexpr (kPlainLoad || kBufVgpr) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      cur.a_off[i] = sw ? nxt.a_off[i] : cur.a_off[i];
-      cur.b_off[i] = sw ? nxt.b_off[i] : cur.b_off[i];
+    for (int i = 0; i < 8; ++i) probe_buf[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  // piece pc (0..3 = A rows, 4..7 = B rows of this wave) of the cursor's stage -> LDS at M0.  The s_nop covers a base
+  // that hipcc has just re-read from an SGPR spill (v_readlane writes the SGPR, and a VMEM instruction may read it
+  // only 5 wait states later; hipcc pads its own instructions, not ours: without it the DMA fetches from a stale base).
+  auto dma_piece = [&](auto pc_c) {
+    constexpr int pc = decltype(pc_c)::value;
+    P4Src& c = cur;  // (named here: a variable used only inside `if constexpr` arms of a generic lambda is not captured)
+    auto& pb = probe_buf;
+    if constexpr (kBufLds || kBufVgpr) {
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      const uint64_t b = (uint64_t)(pc < 4 ? c.a_base : c.b_base);
+      const u32x4_t srd = {(uint32_t)b, (uint32_t)(b >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+      const uint32_t vo = pc < 4 ? c.a_off[pc] : c.b_off[pc - 4];
+      if constexpr (kBufLds) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(vo), "s"(srd) : "memory");
+      else asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(pb[pc]) : "v"(vo), "s"(srd) : "memory");
+    } else if constexpr (kPlainLoad) {  // a VGPR-destination load of the same bytes (never waited for, never used)
+      if constexpr (pc < 4)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(pb[pc]) : "v"(c.a_off[pc]), "s"(c.a_base) : "memory");
+      else
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(pb[pc]) : "v"(c.b_off[pc - 4]), "s"(c.b_base) : "memory");
+    } else if constexpr (pc < 4) {
+      asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(c.a_off[pc]), "s"(c.a_base) : "memory");
+    } else {
+      asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(c.b_off[pc - 4]), "s"(c.b_base) : "memory");
     }
-    cur.nk = sw ? nxt.nk : cur.nk;
-    d_k = sw ? 0 : d_k;
+  };
+  // hand-over of one operand's half of the cursor, in two parts that each fit one MFMA slot
+  bool sw_a = false, sw_b = false;
+  auto adv_a = [&](int part) {
+    if (part == 0) {
+      ++ka;
+      sw_a = (ka == nka);
+      cur.a_base = sw_a ? nxt.a_base : cur.a_base + 64;
+      nka = sw_a ? nxt.nk : nka;
+      ka = sw_a ? 0 : ka;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cur.a_off[i] = sw_a ? nxt.a_off[i] : cur.a_off[i];
+    }
+  };
+  auto adv_b = [&](int part) {
+    if (part == 0) {
+      ++kb;
+      sw_b = (kb == nkb);
+      cur.b_base = sw_b ? nxt.b_base : cur.b_base + 64;
+      nkb = sw_b ? nxt.nk : nkb;
+      kb = sw_b ? 0 : kb;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cur.b_off[i] = sw_b ? nxt.b_off[i] : cur.b_off[i];
+    }
   };
 
   // ---- fragment read addresses (bytes inside a stage) ------------------------------------------------------------
@@ -167,27 +253,119 @@ __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, con
   f32x16_t acc[4][4];
   frag_t fa[2][4], fb[2][4];  // [set][i or j]
 
-  auto read_frag = [&](int set, int slot, int which) {  // which: 0..3 = A row block, 4..7 = B column block
-    const char* base = smem + slot * kP4Stage;
+  auto read_frag = [&](int set, uint32_t slot_off, int which) {  // which: 0..3 = A row block, 4..7 = B column block
+    const char* base = smem + slot_off;
     if (which < 4) fa[set][which] = *reinterpret_cast<const frag_t*>(base + a_rd[set] + which * 2048);
     else fb[set][which - 4] = *reinterpret_cast<const frag_t*>(base + b_rd[set] + (which - 4) * 2048);
   };
 
-  // ---- prologue: fill the ring ------------------------------------------------------------------------------------
+  // ---- prologue: stages 0 .. NS - 3 whole, the first half of stage NS - 2 (its second half goes out in phase A of
+  // the first stage, as in steady state) --------------------------------------------------------------------------
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 3> I3;
+  typedef std::integral_constant<int, 4> I4;
+  typedef std::integral_constant<int, 5> I5;
+  typedef std::integral_constant<int, 6> I6;
+  typedef std::integral_constant<int, 7> I7;
 #pragma unroll
-  for (int st = 0; st < NS; ++st) {
-#pragma unroll
-    for (int pc = 0; pc < kP4Pieces; ++pc) dma_piece(st, pc);
-    dma_advance();
+  for (int st = 0; st < NS - 1; ++st) {
+    const uint32_t l = dma_lds + (uint32_t)st * (uint32_t)kP4Stage;
+    dma_m0(l, I0{}); asm volatile("s_nop 0"); dma_piece(I0{});
+    dma_m0(l, I1{}); asm volatile("s_nop 0"); dma_piece(I1{});
+    dma_m0(l, I2{}); asm volatile("s_nop 0"); dma_piece(I2{});
+    dma_m0(l, I3{}); asm volatile("s_nop 0"); dma_piece(I3{});
+    if (st < NS - 2) {
+      dma_m0(l, I4{}); asm volatile("s_nop 0"); dma_piece(I4{});
+      dma_m0(l, I5{}); asm volatile("s_nop 0"); dma_piece(I5{});
+      dma_m0(l, I6{}); asm volatile("s_nop 0"); dma_piece(I6{});
+      dma_m0(l, I7{}); asm volatile("s_nop 0"); dma_piece(I7{});
+      adv_a(0); adv_a(1); adv_b(0); adv_b(1);
+    }
   }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP4Pieces * (NS - 1)) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP4Pieces * (NS - 3) + 4) : "memory");  // stage 0 has landed
   P4_BARRIER();
 #pragma unroll
-  for (int w = 0; w < 8; ++w) read_frag(0, 0, w);
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+  for (int w = 0; w < 8; ++w) read_frag(0, 0u, p4_read_order(w));
 
   // ---- main loop: this workgroup's items, each a run of branch-free stages -----------------------------------------
-  int slot = 0, slot_next = 1;  // g % NS, (g + 1) % NS for the running stage index g
+  // LDS byte offsets of the ring slots of the running stage index g: g % NS, (g + 1) % NS, and this wave's DMA
+  // destinations in slots (g - 1) % NS, (g - 2) % NS
+  uint32_t off_cur = 0, off_next = kP4Stage;
+  uint32_t dst_m1 = dma_lds + (NS - 1) * kP4Stage, dst_m2 = dma_lds + (NS - 2) * kP4Stage;
+  // One stage = 32 MFMA slots L = 16 * phase + t.  What rides behind each MFMA is laid out so that no slot carries
+  // more than one memory instruction or ~7 scalar / 4 vector instructions (with one wave per SIMD an overfull slot is
+  // matrix-pipe idle time), in groups of four slots q = t / 4:
+  //     t % 4 == 0   two ds_read_b128 of the next phase's fragments
+  //     t % 4 == 1   M0 <- destination of the group's DMA piece
+  //     t % 4 == 2   the DMA piece (phase A: B-row pieces 4..7 of the cursor's stage; phase B: A-row pieces 0..3 of the next)
+  //     t % 4 == 3   cursor hand-over (phase A: the A half, whose pieces went out in the previous phase B; phase B: the
+  //                  B half), ring rotation
+  // RELAX: the stage runs right after an epilogue that issued 32 global stores behind the DMA pieces this stage waits
+  // for, so 32 more operations may be outstanding at its counted wait.
+  auto stage = [&](auto relax_c) {
+    constexpr bool RELAX = decltype(relax_c)::value;
+    auto extras = [&](auto l_c) {
+      constexpr int L = decltype(l_c)::value, t = L & 15, q = t >> 2, r = t & 3;
+      constexpr bool phase_b = L >= 16;
+      if constexpr (r == 0 && !kNoRead) {
+        read_frag(phase_b ? 0 : 1, phase_b ? off_next : off_cur, p4_read_order(2 * q));
+        read_frag(phase_b ? 0 : 1, phase_b ? off_next : off_cur, p4_read_order(2 * q + 1));
+      }
+      if constexpr (r == 1 && !kNoDma) {
+        if constexpr (phase_b) dma_m0(dst_m1, std::integral_constant<int, q>{});
+        else dma_m0(dst_m2, std::integral_constant<int, 4 + q>{});
+      }
+      if constexpr (r == 2 && !kNoDma) {
+        if constexpr (phase_b) dma_piece(std::integral_constant<int, q>{});
+        else dma_piece(std::integral_constant<int, 4 + q>{});
+      }
+      if constexpr (L == 3) adv_a(0);
+      if constexpr (L == 7) adv_a(1);
+      if constexpr (L == 19) adv_b(0);
+      if constexpr (L == 23) adv_b(1);
+      if constexpr (L == 31) {  // ring rotation (every piece and read of this stage has been issued)
+        dst_m2 = dst_m1;
+        dst_m1 = dma_lds + off_cur;
+        off_cur = off_next;
+        off_next = (off_next + kP4Stage == NS * kP4Stage) ? 0u : off_next + kP4Stage;
+      }
+    };
+    auto mfma_at = [&](auto l_c) {
+      constexpr int L = decltype(l_c)::value, t = L & 15, i = t >> 2, j = t & 3, set = L >> 4;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+      extras(l_c);
+      P4_FENCE();
+    };
+#define P4_M(n) mfma_at(std::integral_constant<int, n>{})
+    // phase A: sub-step 0 | reads of sub-step 1 | B-row pieces of the cursor's stage into slot g - 2
+    P4_M(0); P4_M(1); P4_M(2); P4_M(3); P4_M(4); P4_M(5); P4_M(6); P4_M(7);
+    P4_M(8); P4_M(9); P4_M(10); P4_M(11); P4_M(12); P4_M(13); P4_M(14); P4_M(15);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP4Pieces * (NS - 3) + (RELAX ? 32 : 0)) : "memory");  // stage g + 1 landed
+    P4_FENCE();
+    if (!kNoBar) P4_BARRIER();
+    P4_FENCE();
+    // phase B: sub-step 1 | reads of (g + 1, sub-step 0) | A-row pieces of the next stage into slot g - 1
+    P4_M(16); P4_M(17); P4_M(18); P4_M(19); P4_M(20); P4_M(21); P4_M(22); P4_M(23);
+    P4_M(24); P4_M(25); P4_M(26); P4_M(27); P4_M(28); P4_M(29); P4_M(30); P4_M(31);
+#undef P4_M
+  };
+  auto run_stages = [&](int nk, bool relax) {
+    // the first two stages after an epilogue are peeled: their counted waits may leave that epilogue's stores in flight
+    // (stage s is issued in phase B (s - 4) / phase A (s - 3): both stages' needs went out before the stores)
+    if (relax) {
+      stage(std::true_type{});
+      stage(std::true_type{});
+    } else {
+      stage(std::false_type{});
+      stage(std::false_type{});
+    }
+#pragma unroll 1
+    for (int k = 2; k < nk; ++k) stage(std::false_type{});
+  };
+
+  bool relax = false;  // did this wave's previous epilogue issue exactly its 32 stores (and nothing it waited for after them)?
 #pragma unroll 1
   for (int c_item = first_item; c_item < n_items; c_item += stride) {
     const P4Item cit = p4_item(p, c_item, ntiles);
@@ -198,77 +376,160 @@ __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-#pragma unroll 1
-    for (int k = 0; k < cit.nk; ++k) {
-      // phase A: MFMAs of sub-step 0, fragment reads of sub-step 1
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int i = t >> 2, j = t & 3;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
-        if (t < 8) read_frag(1, slot, t);
-        P4_FENCE();
-      }
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): slot `slot` is no longer read by this wave
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP4Pieces * (NS - 2)) : "memory");  // stage g + 1 has landed
-      P4_FENCE();
-      P4_BARRIER();
-      P4_FENCE();
-      // phase B: MFMAs of sub-step 1, fragment reads of (g + 1, sub-step 0), DMA of stage g + NS into slot g % NS
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int i = t >> 2, j = t & 3;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
-        if (t < 8) read_frag(0, slot_next, t);
-        else dma_piece(slot, t - 8);
-        P4_FENCE();
-      }
-      dma_advance();
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-      P4_FENCE();
-      slot = slot_next;
-      slot_next = (slot_next + 1 == NS) ? 0 : slot_next + 1;
-    }
+    run_stages(cit.nk, relax);
 
-    // tile finished: epilogue straight from the accumulators --------------------------------------------------------
+    // ---- tile finished: epilogue straight from the accumulators ---------------------------------------------------
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // last MFMA -> accumulator reads inside asm statements below
     int e_lane = lane;
     asm volatile("" : "+v"(e_lane));  // opaque: nothing below is hoisted above the stage loop (register pressure)
     const int half = e_lane >> 5;
+    const int gn0 = cit.n0 + wn * 128 + 8 * half;  // + 32 j + 16 pr
+    // One (i, j, pr) group = 8 consecutive columns of one output row per lane.  The accumulator elements are read with
+    // v_accvgpr_read at the point of use (asm, "a" operands): left to itself the register allocator copies all 256 of
+    // them into VGPRs at the loop exit and spills loop-carried address registers to make room.
+    auto take8 = [&](auto i_c, auto j_c, auto pr_c, float (&v)[8]) {
+      constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, pr = decltype(pr_c)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // vdst = column group 2 pr (n = 16 pr + 4 half + e), src = group 2 pr + 1 (n = 16 pr + 8 + 4 half + e)
-            const uint32_t lo = __builtin_bit_cast(uint32_t, acc[i][j][8 * pr + e]);
-            const uint32_t hi = __builtin_bit_cast(uint32_t, acc[i][j][8 * pr + 4 + e]);
-            const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-            v[e] = __builtin_bit_cast(float, (uint32_t)r[0]);
-            v[4 + e] = __builtin_bit_cast(float, (uint32_t)r[1]);
-          }
-          const int gn = cit.n0 + wn * 128 + j * 32 + 16 * pr + 8 * half;
-          if (gm < p.M && gn < p.N)
-            gemm_epilogue8<bf16_t, ACT>(p, cit.kz, gm, gn, v);  // split-K slabs are launched with ACT = none
-        }
+      for (int e = 0; e < 4; ++e) {
+        // vdst = column group 2 pr (n = 16 pr + 4 half + e), src = group 2 pr + 1 (n = 16 pr + 8 + 4 half + e)
+        uint32_t lo, hi;
+        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\ts_nop 1"
+                     : "=&v"(lo), "=&v"(hi)
+                     : "a"(acc[i][j][8 * pr + e]), "a"(acc[i][j][8 * pr + 4 + e]));
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        v[e] = __uint_as_float(r[0]);
+        v[4 + e] = __uint_as_float(r[1]);
       }
+    };
+    const bool rows_all = cit.m0 + wm * 128 + 128 <= p.M;  // every row of the wave's 128 is in range
+    const bool fast = !p.slabs && !p.out_f32 && !p.a_scale && !p.b_scale && !p.P && cit.n0 + 256 <= p.N &&
+                      (!p.R || rows_all);  // the residual path counts its stores (see half_tile)
+    relax = fast && rows_all;  // exactly 32 stores were issued behind the DMA pieces the next two stages wait for
+    if (fast) {
+      // bf16 C with optional bias / activation / LayerScale / residual.  Column vectors come through the scalar cache
+      // (no vmcnt wait); the residual is loaded for half of the wave's columns at a time, all loads of a half ahead of
+      // that half's stores (a vector load issued after a store can only be waited for together with the store).
+      const float* bias_w = p.bias ? p.bias + cit.n0 + wn * 128 : nullptr;
+      const float* cs_w = p.colscale ? p.colscale + cit.n0 + wn * 128 : nullptr;
+      const bool upper = half != 0;
+      int64_t crow[4];
+      bool okr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
+        okr[i] = gm < p.M;
+        crow[i] = row_off(p.c_map, (uint32_t)(okr[i] ? gm : p.M - 1)) + gn0;
+      }
+      // The residual loads are issued and waited for by hand (asm, counted vmcnt).  Left to hipcc, their pending-load
+      // state leaks out of the epilogue — its scoreboard cannot tell that they are all consumed — and it parks an
+      // s_waitcnt vmcnt(0) inside the next tile's stage loop, in front of the ds_reads that reuse those registers:
+      // the LDS-DMA pipeline then drains every stage.  The stores stay ordinary stores; a store is only issued when
+      // some lane's row is in range, which is why the counted waits below assume the row block is in range for the
+      // wave (otherwise the wave-uniform `rows_ok` falls back to a full drain).
+      auto half_tile = [&](auto h_c, auto r_c) {  // column groups g8 = 4 h .. 4 h + 3 (j = 2 h, 2 h + 1)
+        constexpr int h = decltype(h_c)::value;
+        constexpr bool HAS_R = decltype(r_c)::value;
+        bf16x8_t res[4][4];
+        if constexpr (HAS_R) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
+            const bf16_t* rrow =
+                reinterpret_cast<const bf16_t*>(p.R) + row_off(p.r_map, (uint32_t)(gm < p.M ? gm : p.M - 1)) + gn0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)  // asm: hipcc must not see these loads (comment at the top of half_tile)
+              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(res[i][g]) : "v"(rrow + 16 * (4 * h + g)) : "memory");
+          }
+        }
+        auto group = [&](auto g_c) {
+          constexpr int g = decltype(g_c)::value, g8 = 4 * h + g, j = g8 >> 1, pr = g8 & 1;
+          float bias[8], cs[8];
+          if (bias_w) p4_colvec(bias_w + 16 * g8, upper, bias);
+          if (cs_w) p4_colvec(cs_w + 16 * g8, upper, cs);
+          auto row = [&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            float v[8];
+            take8(i_c, std::integral_constant<int, j>{}, std::integral_constant<int, pr>{}, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+            if (bias_w) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += bias[e];
+            }
+            if constexpr (ACT != CMB_ACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
+            }
+            if (cs_w) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= cs[e];
+            }
+            if constexpr (HAS_R) {
+              // load number 4 i + g of this half; behind it: 15 - (4 i + g) loads and the 4 g + i stores issued so far
+              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(res[i][g]) : "n"(15 - 3 * i + 3 * g));
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)res[i][g][e];
+            }
+            if (okr[i])
+              *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16_t*>(p.C) + crow[i] + 16 * g8) =
+                  cvt8_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            P4_FENCE();
+          };
+          row(I0{}); row(I1{}); row(I2{}); row(I3{});
+        };
+        group(I0{}); group(I1{}); group(I2{}); group(I3{});
+      };
+#ifndef P4_X2
+      if (p.R) {
+        half_tile(I0{}, std::true_type{});
+        half_tile(I1{}, std::true_type{});
+      } else
+#endif
+      {
+        half_tile(I0{}, std::false_type{});
+        half_tile(I1{}, std::false_type{});
+      }
+    } else {
+      // every other epilogue form (split-K slabs, fp32 C with beta, pre-activation copy, ragged N): group by group
+      // through the shared helper
+      auto slow = [&](auto i_c, auto j_c, auto pr_c) {
+        constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, pr = decltype(pr_c)::value;
+        float v[8];
+        take8(i_c, j_c, pr_c, v);
+        const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
+        const int gn = gn0 + 32 * j + 16 * pr;
+        if (gm < p.M && gn < p.N) gemm_epilogue8<bf16_t, ACT>(p, cit.kz, gm, gn, v);  // slabs are launched with ACT none
+        P4_FENCE();
+      };
+      auto slow_row = [&](auto i_c) {
+        slow(i_c, I0{}, I0{}); slow(i_c, I0{}, I1{}); slow(i_c, I1{}, I0{}); slow(i_c, I1{}, I1{});
+        slow(i_c, I2{}, I0{}); slow(i_c, I2{}, I1{}); slow(i_c, I3{}, I0{}); slow(i_c, I3{}, I1{});
+      };
+#ifndef P4_X1
+      slow_row(I0{}); slow_row(I1{}); slow_row(I2{}); slow_row(I3{});
+#endif
+      // The helper's loads sit in run-time branches whose uses the compiler cannot pair up: it would carry "a load may
+      // still be pending" into the next tile and park an s_waitcnt vmcnt(0) inside the stage loop (draining the
+      // LDS-DMA every stage).  Retire them here, where it only costs this rare path a store drain.
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
     // the cursor is now inside item c_item + stride (nk >= NS is a launch condition): describe the one after it
     const int n2 = c_item + 2 * stride;
     nxt = src_of(n2 <= last_item ? n2 : last_item);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+  if constexpr (kPlainLoad || kBufVgpr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(probe_buf[i]));
+  }
 }
 
-template <int ACT, int NS>
+template <int ACT, int NS, int VAR>
 int launch_p4_act(GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem = NS * kP4Stage;
   static bool attr_done = false;
   static int n_cu = 0;
-  auto kern = gemm_nt_p4_kernel<ACT, NS>;
+  auto kern = gemm_nt_p4_kernel<ACT, NS, VAR>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
         hipSuccess)
@@ -290,21 +551,43 @@ int launch_p4_act(GemmParams& p, int splits, hipStream_t s) {
   return CMB_OK;
 }
 
-template <int NS>
+template <int NS, int VAR>
 int launch_p4_ns(GemmParams& p, int splits, hipStream_t s) {
   switch (p.slabs ? CMB_ACT_NONE : p.act) {
-    case CMB_ACT_GELU_ERF: return launch_p4_act<CMB_ACT_GELU_ERF, NS>(p, splits, s);
-    case CMB_ACT_GELU_TANH: return launch_p4_act<CMB_ACT_GELU_TANH, NS>(p, splits, s);
-    case CMB_ACT_QUICK_GELU: return launch_p4_act<CMB_ACT_QUICK_GELU, NS>(p, splits, s);
-    case CMB_ACT_SILU: return launch_p4_act<CMB_ACT_SILU, NS>(p, splits, s);
-    default: return launch_p4_act<CMB_ACT_NONE, NS>(p, splits, s);
+    case CMB_ACT_GELU_ERF: return launch_p4_act<CMB_ACT_GELU_ERF, NS, VAR>(p, splits, s);
+    case CMB_ACT_GELU_TANH: return launch_p4_act<CMB_ACT_GELU_TANH, NS, VAR>(p, splits, s);
+    case CMB_ACT_QUICK_GELU: return launch_p4_act<CMB_ACT_QUICK_GELU, NS, VAR>(p, splits, s);
+    case CMB_ACT_SILU: return launch_p4_act<CMB_ACT_SILU, NS, VAR>(p, splits, s);
+    default: return launch_p4_act<CMB_ACT_NONE, NS, VAR>(p, splits, s);
   }
 }
 
 }  // namespace
 
-int launch_gemm_p4_bf16(GemmParams& p, int splits, int ns, hipStream_t s) {
-  return ns == 4 ? launch_p4_ns<4>(p, splits, s) : launch_p4_ns<5>(p, splits, s);
+// var: ablation bits of the kernel template (0 = production); ablations exist for act = none in lab builds only
+int launch_gemm_p4_bf16(GemmParams& p, int splits, int ns, int var, hipStream_t s) {
+#ifdef CMB_P4_QUICK  // compile-time experiments: one instantiation only
+  return launch_p4_act<CMB_ACT_NONE, 5, 0>(p, splits, s);
+#else
+  switch (var) {
+#ifdef CMB_GEMM_LAB
+    case 1: return launch_p4_act<CMB_ACT_NONE, 5, 1>(p, splits, s);
+    case 2: return launch_p4_act<CMB_ACT_NONE, 5, 2>(p, splits, s);
+    case 3: return launch_p4_act<CMB_ACT_NONE, 5, 3>(p, splits, s);
+    case 4: return launch_p4_act<CMB_ACT_NONE, 5, 4>(p, splits, s);
+    case 5: return launch_p4_act<CMB_ACT_NONE, 5, 5>(p, splits, s);
+    case 6: return launch_p4_act<CMB_ACT_NONE, 5, 6>(p, splits, s);
+    case 8: return launch_p4_act<CMB_ACT_NONE, 5, 8>(p, splits, s);
+    case 16: return launch_p4_act<CMB_ACT_NONE, 5, 16>(p, splits, s);
+    case 64: return launch_p4_act<CMB_ACT_NONE, 5, 64>(p, splits, s);
+    case 66: return launch_p4_act<CMB_ACT_NONE, 5, 66>(p, splits, s);
+    case 128: return launch_p4_act<CMB_ACT_NONE, 5, 128>(p, splits, s);
+    case 130: return launch_p4_act<CMB_ACT_NONE, 5, 130>(p, splits, s);
+    case 18: return launch_p4_act<CMB_ACT_NONE, 5, 18>(p, splits, s);
+#endif
+    default: return launch_p4_ns<5, 0>(p, splits, s);
+  }
+#endif
 }
 
 }  // namespace cmb_gemm_detail

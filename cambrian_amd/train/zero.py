@@ -4,9 +4,10 @@ reference: scripts/zero2.json:1-22 — gradient partitioning + optimizer-state p
 Layout: parameters are re-homed into a few flat fp32 *buckets* (default 64 MiB; xGMI is point-to-point, so few large
 collectives), each padded to a multiple of the world size and cut into ``world`` equal shards; rank r owns shard r of
 every bucket.  Per step
-  * backward: a bucket's gradients are copied into its flat gradient buffer by post-accumulate hooks; when the last one
-    has arrived an async ``reduce_scatter`` (RCCL's own stream) delivers the SUM of the owned shard — it overlaps the
-    rest of the backward pass;
+  * backward: a bucket's gradients are ADDED into its flat gradient buffer by post-accumulate hooks (so micro-batches
+    accumulate, as ``--gradient_accumulation_steps`` of the reference launch scripts needs); on the LAST micro-batch of
+    a step — every backward outside ``no_sync()`` — the arrival of a bucket's last gradient launches an async
+    ``reduce_scatter`` (RCCL's own stream) that delivers the SUM of the owned shard and overlaps the rest of backward;
   * ``step()``: waits, turns sums into means, runs AdamW (torch's fused multi-tensor kernel) on the owned shards only —
     exp_avg / exp_avg_sq exist for 1/world of the parameters — and ``all_gather``s the updated shards straight into the
     flat parameter buckets, of which the module's parameters are views (no copy back).
@@ -74,6 +75,7 @@ class Zero2AdamW:
                                        **({"fused": True} if fused else {}))
         self._where = {}
         self._handles = []
+        self._sync = True  # False inside no_sync(): accumulate only, no collective
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
@@ -89,20 +91,41 @@ class Zero2AdamW:
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         b, i = self._where[p]
-        b.grad_views[i].copy_(p.grad)
+        if b.work is not None or b.pending <= 0:
+            raise RuntimeError("Zero2AdamW: a gradient arrived after this step's reduce-scatter was launched; run every "
+                               "micro-batch but the last one of a step under `with opt.no_sync():`")
+        b.grad_views[i].add_(p.grad)  # accumulate (flat_grad is zeroed by step())
         p.grad = None  # the full gradient is not kept: ZeRO-2 holds 1/world of it after the reduce-scatter
+        if not self._sync:
+            return
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
+
+    def no_sync(self):
+        """Context manager for gradient accumulation (same contract as DistributedDataParallel.no_sync): backward passes
+        inside it only accumulate into the flat gradient buckets; the first backward outside it reduces."""
+        opt = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                self_inner.prev, opt._sync = opt._sync, False
+
+            def __exit__(self_inner, *exc):
+                opt._sync = self_inner.prev
+
+        return _NoSync()
 
     # ---- optimizer side ------------------------------------------------------------------------------------------
     def step(self) -> None:
         gathers = []
         for b, s in zip(self.buckets, self._shards):
-            if b.pending != 0:  # some parameter got no gradient this step: its slot must still enter the collective as 0
+            if b.work is None and (b.pending != 0 or self.world == 1):
+                # some parameter got no gradient on the last micro-batch (its slot enters the collective as whatever the
+                # earlier micro-batches accumulated, 0 if none), or the whole step ran under no_sync()
                 for i, p in enumerate(b.params):
                     if p.grad is not None:
-                        b.grad_views[i].copy_(p.grad)
+                        b.grad_views[i].add_(p.grad)
                         p.grad = None
                 self._launch(b)
             if b.work is not None:

@@ -25,8 +25,8 @@ SHAPES = [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 512, 256), (30
 
 
 # tile_hint: 256x256 tile; 2560 / 2561 = 8-wave kernel, schedule 0 (8-phase ping-pong) / 1 (in-wave pipeline, 1 barrier
-# per K-tile); 2570 / 2574 = persistent 4-wave kernel with an LDS ring of 5 / 4 stages
-SCHEDS = [2560, 2561, 2570, 2574]
+# per K-tile); 2570 / 2574 = persistent 4-wave kernel with an LDS ring of 5 / 4 stages, 2604 = its spread-DMA schedule
+SCHEDS = [2560, 2561, 2570]
 
 
 @pytest.mark.parametrize("tile", SCHEDS)
@@ -123,3 +123,41 @@ def test_gemm256_rowmaps(dev, tile):
     mask = torch.ones(B, S, dtype=torch.bool)
     mask[:, p0:p0 + side * (side + 1)].view(B, side, side + 1)[:, :, :side] = False
     assert torch.equal(hd.cpu()[mask], hidden[mask])   # untouched rows bit-identical
+
+
+@pytest.mark.parametrize("tile", [2570])
+@pytest.mark.parametrize("mode", ["plain", "bias_gelu", "bias_silu", "bias_cs_res", "res", "cs"])
+@pytest.mark.parametrize("M", [1024, 1000, 2300])
+def test_gemm_p4_register_epilogue(dev, M, mode, tile):
+    """The persistent kernel's epilogue leaves from the accumulators (permlane32 swap -> 16-byte stores) with the column
+    vectors through the scalar cache and hand-counted residual loads: every combination, full and ragged row tiles
+    (ragged rows of a residual launch take the generic path), several tiles per workgroup (N = 768 -> 3 column tiles)."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(M + len(mode))
+    N, K = 768, 320
+    dt = torch.bfloat16
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2
+    bias, cs, res = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    a_, w_, res_ = a.to(dt).float(), w.to(dt).float(), res.to(dt).float()
+    ref = a_ @ w_.T
+    kw = {}
+    if "bias" in mode:
+        ref = ref + bias
+        kw["bias"] = bias.to(dev)
+    if "gelu" in mode:
+        ref = F.gelu(ref)
+        kw["act"] = L.ACT_CODES["gelu_erf"]
+    if "silu" in mode:
+        ref = F.silu(ref)
+        kw["act"] = L.ACT_CODES["silu"]
+    if "cs" in mode:
+        ref = ref * cs
+        kw["colscale"] = cs.to(dev)
+    if "res" in mode:
+        ref = ref + res_
+        kw["residual"] = res.to(dev, dt)
+    out = ops.k_gemm(a.to(dev, dt), w.to(dev, dt), tile=tile, **kw)
+    assert rel_err(out, ref) < 1e-2
+    out128 = ops.k_gemm(a.to(dev, dt), w.to(dev, dt), tile=128, **kw)
+    # same bf16 rounding of the same fp32 values up to the accumulation order: a few bf16 ulps at most
+    assert (out.float() - out128.float()).abs().max().item() <= 4e-2 * ref.abs().max().item() * 2 ** -7 * 8

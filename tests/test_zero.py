@@ -25,7 +25,7 @@ def _data(world, step):
     return [torch.randn(8, 16, generator=torch.Generator().manual_seed(100 * step + k)) for k in range(world)]
 
 
-def _reference(world, steps, lr, wd):
+def _reference(world, steps, lr, wd, accum=1):
     m = _model()
     unused = torch.nn.Parameter(torch.ones(7))
     params = list(m.parameters()) + [unused]
@@ -35,7 +35,8 @@ def _reference(world, steps, lr, wd):
         for k in range(world):
             for p in params:
                 p.grad = None
-            m(_data(world, step)[k]).pow(2).mean().backward()
+            for mb in range(accum):           # micro-batches accumulate (sum), as loss.backward() twice does
+                m(_data(world, step * accum + mb)[k]).pow(2).mean().backward()
             g = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in params]
             grads = g if grads is None else [a + b for a, b in zip(grads, g)]
         for p, g in zip(params, grads):
@@ -44,7 +45,7 @@ def _reference(world, steps, lr, wd):
     return [p.detach().clone() for p in params]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, accum=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from cambrian_amd.train.dp import init_distributed
@@ -59,21 +60,36 @@ def _worker(rank, world, port, q):
     assert opt.state_bytes() < 0.6 * full                                    # Adam moments are sharded
     steps = 3
     for step in range(steps):
-        m(_data(world, step)[rank]).pow(2).mean().backward()
+        for mb in range(accum - 1):           # gradient accumulation: no collective until the last micro-batch
+            with opt.no_sync():
+                m(_data(world, step * accum + mb)[rank]).pow(2).mean().backward()
+        m(_data(world, step * accum + accum - 1)[rank]).pow(2).mean().backward()
         opt.step()
         opt.zero_grad()
-    want = _reference(world, steps, 1e-2, 0.1)
+    if accum > 1:                             # a second un-synchronised backward in one step must fail loudly
+        m(_data(world, 0)[rank]).pow(2).mean().backward()
+        try:
+            m(_data(world, 1)[rank]).pow(2).mean().backward()
+            q.put((rank, False))
+            return
+        except RuntimeError:
+            pass
+    want = _reference(world, steps, 1e-2, 0.1, accum)
     ok = all(torch.allclose(p.detach(), w, atol=1e-6, rtol=1e-5) for p, w in zip(params, want))
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_zero2_world2_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_zero2_world2_gloo(accum):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, accum)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)

@@ -9,20 +9,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cambrian_amd import ops, lib as L  # noqa: E402
 
 M, N, K = (int(x) for x in sys.argv[1:4])
-tile = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+tile = (sys.argv[4] if sys.argv[4] == "blas" else int(sys.argv[4])) if len(sys.argv) > 4 else 256
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 act = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 dev = torch.device("cuda:0")
 a = torch.randn(M, K, device=dev).to(torch.bfloat16)
 w = torch.randn(N, K, device=dev).to(torch.bfloat16)
 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+def run():
+    if tile == "blas":
+        torch.matmul(a, w.T, out=out)
+    else:
+        ops.k_gemm(a, w, out=out, tile=tile, act=act)
+
+
 for _ in range(iters):
-    ops.k_gemm(a, w, out=out, tile=tile, act=act)
+    run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters):
-    ops.k_gemm(a, w, out=out, tile=tile, act=act)
+    run()
 e1.record()
 torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / iters * 1e-3

@@ -17,6 +17,7 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--variants", default="128,2560,2570,2574,blas")
+ap.add_argument("--shapes", default="")
 args = ap.parse_args()
 
 # (M, N, K, act, bias)  — the in-step shapes of bench.py at 16 img/GPU, by time (gpurun_out/gemm_shapes_b16.json)
@@ -29,6 +30,8 @@ SHAPES = [
 if args.quick:
     SHAPES = SHAPES[:4] + SHAPES[13:14]
 variants = args.variants.split(",")
+if args.shapes:
+    SHAPES = [tuple(int(x) for x in t.split("x")) for t in args.shapes.split(",")]
 
 
 def run(v, a, w, out, bias, act):
