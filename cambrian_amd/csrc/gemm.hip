@@ -242,7 +242,7 @@ static int tile_override() {
 }
 static bool use_tile256(int M, int N, int splits, int hint) {
   const int ov = hint ? hint : tile_override();
-  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2574 || (ov >= 2600 && ov < 2856)) return true;
+  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2580 || (ov >= 2600 && ov < 3000)) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -311,16 +311,20 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   }
   int rc;
   if constexpr (sizeof(T) == 2) {
-    // tile_hint / CMB_GEMM_TILE: 128 | 256 (auto kernel) | 2560 / 2561 (8-wave kernel, schedule 0 / 1) | 2570 / 2574
-    // (persistent 4-wave kernel, ring of 5 / 4 stages)
+    // tile_hint / CMB_GEMM_TILE: 0 = cost model (128x128 or the 8-wave 256x256 kernel) | 128 | 256 / 2560 / 2561 (8-wave
+    // kernel, schedule 0 / 0 / 1) | 2570 (persistent 4-wave kernel, gemm_p4.hip) | 2580 (persistent 256x128, two workgroups
+    // per CU) | 2600 + bits (ablations of the 4-wave kernel, lab builds).  The persistent kernels are opt-in: on the
+    // path's shapes they measure within +-7 % of the 8-wave kernel (profiles/r02_gemm_lab.md), so the latter stays default.
     const int ov = d->tile_hint ? d->tile_hint : tile_override();
-    const int ns = 5;
+    const bool want_p4 = ov == 2570 || (ov >= 2600 && ov < 3000);
     if (!use_tile256(p.M, p.N, splits, d->tile_hint) || !tile_span_fits_u32(p.a_map, p.ldb))
       rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
-    else if (ov == 2560 || ov == 2561 || !p4_ok(p, splits, ns))
-      rc = launch_gemm256_bf16(p, splits, ov == 2561 ? 1 : 0, s);
+    else if (ov == 2580 && p4_ok(p, splits, 3))
+      rc = launch_gemm_p2_bf16(p, splits, s);
+    else if (want_p4 && p4_ok(p, splits, 5))
+      rc = launch_gemm_p4_bf16(p, splits, 5, ov >= 2600 ? ov - 2600 : 0, s);
     else
-      rc = launch_gemm_p4_bf16(p, splits, ns, (ov >= 2600 && ov < 2856) ? ov - 2600 : 0, s);
+      rc = launch_gemm256_bf16(p, splits, ov == 2561 ? 1 : 0, s);
   } else {
     rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   }

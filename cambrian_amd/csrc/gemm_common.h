@@ -108,7 +108,10 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
     for (int e = 0; e < 8; ++e) v[e] += bb[e];
   }
   if (p.P) Vec8<T>::store(reinterpret_cast<T*>(p.P) + row_off(p.p_map, (uint32_t)gm) + gn, v);
-  if constexpr (ACT != CMB_ACT_NONE) {
+  if constexpr (ACT == CMB_ACT_GELU_ERF && std::is_same<T, bf16_t>::value) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = cmb_gelu_erf_fast(v[e]);  // bf16 operands / results: common.h
+  } else if constexpr (ACT != CMB_ACT_NONE) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
   }
@@ -157,5 +160,7 @@ int launch_gemm256_bf16(GemmParams& p, int splits, int sched, hipStream_t s);
 
 // gemm_p4.hip: persistent 256x256 bf16 tile, 4 waves x (128 x 128), LDS ring of `ns` (4 or 5) 32-deep stages.
 int launch_gemm_p4_bf16(GemmParams& p, int splits, int ns, int var, hipStream_t s);
+// gemm_p4.hip: persistent 256x128 bf16 tile, 4 waves x (128 x 64), two workgroups per CU, LDS ring of 3 stages.
+int launch_gemm_p2_bf16(GemmParams& p, int splits, hipStream_t s);
 
 }  // namespace cmb_gemm_detail
