@@ -283,12 +283,16 @@ class CambrianMetaForCausalLM(ABC):
             group_out = []
             for g, query_num in enumerate(cfg.query_num_list):                       # :382-402
                 qside = int(query_num ** 0.5)
-                if qside != side:
-                    raise NotImplementedError("query groups with query_num != image_token_len need the bilinear "
-                                              "resize backward (cambrian_arch.py:395-401); not used by any release config")
+                # the reference re-views the collator's masks per group (`.view(bs * q * q, -1)`, :283), whatever q is
+                masks_g = masks_u8 if qside == side else self._masks_u8(image_aux_attention_masks_list, bs, qside, feats)
                 vq = model.vision_query[g].to(dtype)
                 q2 = vq.view(1, vh).expand(bs * query_num, vh).contiguous()
-                out = getattr(model, f"vision_sampler_{g}").forward_fused(q2, ctx_b, feats, masks_u8, holders, bs, qside)
+                out = getattr(model, f"vision_sampler_{g}").forward_fused(q2, ctx_b, feats, masks_g, holders, bs, qside)
+                if qside != side:                                                    # :395-401 (S5): fp32 bilinear to the
+                    out = out.view(bs, qside, qside, -1).permute(0, 3, 1, 2)         # final grid, align_corners=False
+                    out = torch.nn.functional.interpolate(out.float(), size=(side, side), mode="bilinear",
+                                                          align_corners=False).to(dtype)
+                    out = out.permute(0, 2, 3, 1).reshape(bs * side * side, -1)
                 group_out.append(out)
             image_features = group_out[0] if len(group_out) == 1 else torch.cat(group_out, -1)
             sva_ctx = SvaContext(feats, masks_u8, holders, ctx_b, bs, side)

@@ -94,6 +94,34 @@ def golden_sva():
     print("sva_small.pt", sum(v.numel() for v in fx["state"].values()), "params")
 
 
+def golden_sva_k1024():
+    """The REAL vision_sampler.py at dimensions the HIP kernels accept (hidden 1024, 16 heads x 64, kv windows [1,1,1,4],
+    query grid 4 x 4, one image) so that the fixture replays straight through the HIP module (one hop: reference ->
+    HIP), for q_dim 1024 (connector) and 4096 (in-LLM).  Weights come from tests/golden_recipes.fill_state (not stored:
+    15.8 M / 22 M parameters); parameter gradients are stored as summaries (sum, norm, 3 seeded projections)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from golden_recipes import fill_state, grad_summary, sva_k1024_inputs
+    vs = load_ref_vision_sampler()
+    fx = {}
+    for q_dim in (1024, 4096):
+        seed = 4242 + q_dim
+        hidden, kv_sizes, qside, B = 1024, [1, 1, 1, 4], 4, 1
+        m = vs.VisionTokenSampler(q_dim, hidden, [hidden] * 4, kv_sizes, hidden, 1).float()
+        m.load_state_dict(fill_state(m.state_dict(), seed), strict=True)
+        q, ctx, kvs, masks, w = sva_k1024_inputs(q_dim, hidden, kv_sizes, qside, B, seed)
+        q.requires_grad_(); ctx.requires_grad_()
+        kvs = [k.requires_grad_() for k in kvs]
+        out = m(q, ctx, *kvs, *masks)
+        (out * w).sum().backward()
+        fx[q_dim] = {
+            "cfg": dict(q_dim=q_dim, hidden=hidden, kv_sizes=kv_sizes, qside=qside, B=B, seed=seed),
+            "out": out.detach(), "dq": q.grad, "dctx": ctx.grad, "dkvs": [k.grad for k in kvs],
+            "dparams": {n: grad_summary(p.grad, n, seed) for n, p in m.named_parameters()},
+        }
+        print("sva_k1024 q_dim", q_dim, "out", tuple(out.shape), float(out.detach().abs().max()))
+    torch.save(fx, f"{OUT}/sva_k1024.pt")
+
+
 def golden_towers():
     """Outputs of the installed HF modules (the third-party arithmetic the reference delegates to) on seeded
     small configs; replayed through oracle/towers.py via cambrian_amd/.../weight_maps.py."""
@@ -187,7 +215,13 @@ def golden_collator():
     print("collator_cases.pt written")
 
 
-def golden_arch():
+def golden_arch_groups():
+    """Same, with two query groups [16, 4]: the second group's 2 x 2 queries are resized to the final 4 x 4 grid
+    (cambrian_arch.py:395-401) -> arch_groups_small.pt."""
+    golden_arch(query_nums=[16, 4], out_name="arch_groups_small.pt")
+
+
+def golden_arch(query_nums=None, out_name="arch_small.pt"):
     """The real CambrianMetaForCausalLM.prepare_inputs_labels_for_multimodal (static branch) with fake towers."""
     import torch.nn as nn
     A = load_ref_arch()
@@ -218,7 +252,8 @@ def golden_arch():
     cfg.mm_vision_tower_aux_list = ["a", "b"]
     cfg.mm_vision_tower_aux_token_len_list = token_lens
     cfg.mm_projector_type = "sva"
-    cfg.num_query_group, cfg.query_num_list, cfg.connector_only, cfg.connector_depth = 1, [side * side], False, 2
+    query_nums = query_nums or [side * side]
+    cfg.num_query_group, cfg.query_num_list, cfg.connector_only, cfg.connector_depth = len(query_nums), query_nums, False, 2
     cfg.image_token_len = side * side
     cfg.num_of_vision_sampler_layers, cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers = 2, 0, 1
     cfg._fake_towers = towers
@@ -273,7 +308,7 @@ def golden_arch():
     w = torch.randn_like(emb)
     (emb * w).sum().backward()
     fx = dict(cfg=dict(H=H, vh=vh, side=side, B=B, S=S, V=V, tower_dims=tower_dims, token_lens=token_lens,
-                       connector_depth=2, n_in_llm=2),
+                       connector_depth=2, n_in_llm=2, query_nums=list(query_nums)),
               state={k: v.detach().clone() for k, v in lm.model.state_dict().items()},
               ids=new_ids, pos=new_pos, att=new_att, labels=new_lab, aux_masks=aux_masks, sizes=sizes,
               feats=[f.detach().clone() for f in feats], embeds=emb.detach().clone(),
@@ -281,7 +316,7 @@ def golden_arch():
               final_size=out[8], ctx_final=out[9].detach().clone(), w=w,
               dfeats=[f.grad.clone() for f in feats],
               dparams={n: p_.grad.clone() for n, p_ in lm.model.named_parameters() if p_.grad is not None})
-    torch.save(fx, f"{OUT}/arch_small.pt")
+    torch.save(fx, f"{OUT}/{out_name}")
     print("arch_small.pt written:", sorted(fx["dparams"].keys())[:4], "...")
 
 
@@ -400,7 +435,8 @@ def golden_arch_dynamic():
     cfg.mm_vision_tower_aux_list = ["a", "b"]
     cfg.mm_vision_tower_aux_token_len_list = token_lens
     cfg.mm_projector_type = "sva"
-    cfg.num_query_group, cfg.query_num_list, cfg.connector_only, cfg.connector_depth = 1, [side * side], False, 2
+    query_nums = query_nums or [side * side]
+    cfg.num_query_group, cfg.query_num_list, cfg.connector_only, cfg.connector_depth = len(query_nums), query_nums, False, 2
     cfg.image_token_len = side * side
     cfg.num_of_vision_sampler_layers, cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers = 2, 0, 1
     cfg._fake_towers = towers

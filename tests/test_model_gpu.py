@@ -4,7 +4,10 @@ CPU oracle (oracle/{towers,arch,llama}.py, each pinned to the reference by tests
 
 Stated tolerance (BASELINE.json north_star: "logits within 1e-3 rel of reference"): rel = max|a-b| / max|b|.
 fp32 mode (exact-fp32 MFMA / VALU kernels): logits rel <= 1e-3 (observed ~1e-5).  bf16 mode (production dtype,
-bf16 storage / fp32 accumulate, same as the reference's own bf16 compute): logits rel <= 5e-2 vs the fp32 oracle.
+bf16 storage / fp32 accumulate, same as the reference's own bf16 compute): logits rel <= 2e-2, gradients <= 4e-2 vs the
+fp32 oracle.  Observed (tools/probe_bf16_tolerance.py, round 2): logits 9.2e-3, worst trainable gradient 1.5e-2; against
+the same oracle fed bf16-ROUNDED parameters and inputs 8.2e-3 / 1.9e-2 — i.e. the gap is activation rounding (every
+kernel stores bf16) and accumulation order, not a systematic term; the bounds sit at ~2x what is observed.
 """
 from types import SimpleNamespace
 
@@ -72,7 +75,7 @@ class _SmallTower(nn.Module):
 
 
 def _build(dev, dt, monkeypatch, lm="llama", kinds=("vit", "convnext"), projector="sva", samplers=(2, 0, 2), p0=P0,
-           layers=4, nkv=2, sliding_window=None):
+           layers=4, nkv=2, sliding_window=None, query_nums=None):
     """Small instance of the hot path.  ``lm``: 'llama' | 'phi3'; ``kinds``: the towers; ``projector``: 'sva' or an
     mlpNx_gelu type (BASELINE configs[0]); ``samplers`` = (number, start, stride) of the in-LLM SVA layers."""
     from cambrian_amd.model.language_model import cambrian_llama as CL
@@ -90,7 +93,8 @@ def _build(dev, dt, monkeypatch, lm="llama", kinds=("vit", "convnext"), projecto
         lm_cls = CL.CambrianLlamaForCausalLM
     CL.apply_release_8b_vision_config(cfg, towers=[f"t{i}" for i in range(len(towers))],
                                       token_lens=[t.tokens for t in towers])
-    cfg.image_token_len, cfg.query_num_list, cfg.connector_depth = SIDE * SIDE, [SIDE * SIDE], 2
+    cfg.image_token_len, cfg.query_num_list, cfg.connector_depth = SIDE * SIDE, list(query_nums or [SIDE * SIDE]), 2
+    cfg.num_query_group = len(cfg.query_num_list)
     cfg.num_of_vision_sampler_layers, cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers = samplers
     cfg.image_position, cfg.vision_hidden_size = p0, VH
     if projector != "sva":
@@ -150,7 +154,7 @@ def _oracle_run(model, cfg, towers, batch):
 
 @pytest.mark.parametrize("fused_loss", [False, True])
 @pytest.mark.parametrize("name,dt,tol_logits,tol_grad", [("fp32", torch.float32, 1e-3, 5e-3),
-                                                          ("bf16", torch.bfloat16, 5e-2, 1.5e-1)])
+                                                          ("bf16", torch.bfloat16, 2e-2, 4e-2)])
 def test_end_to_end_logits_loss_and_gradients(dev, monkeypatch, name, dt, tol_logits, tol_grad, fused_loss):
     from cambrian_amd.train.data_layout import synthetic_batch
     model, cfg, towers = _build(dev, dt, monkeypatch)
@@ -219,7 +223,7 @@ def _compare(dev, dt, model, cfg, towers, batch, tol_logits, tol_grad, min_check
     assert worst[1] < tol_grad, f"worst trainable-parameter gradient {worst}"
 
 
-DTYPES = [("fp32", torch.float32, 1e-3, 5e-3), ("bf16", torch.bfloat16, 5e-2, 1.5e-1)]
+DTYPES = [("fp32", torch.float32, 1e-3, 5e-3), ("bf16", torch.bfloat16, 2e-2, 4e-2)]
 
 
 @pytest.mark.parametrize("name,dt,tol_logits,tol_grad", DTYPES)
@@ -246,6 +250,21 @@ def test_config1_single_tower_sva(dev, monkeypatch, name, dt, tol_logits, tol_gr
     batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16],
                             image_res=[56], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
     _compare(dev, dt, model, cfg, towers, batch, tol_logits, tol_grad, min_checked=30)
+
+
+@pytest.mark.parametrize("name,dt,tol_logits,tol_grad", DTYPES)
+def test_two_query_groups_with_resize(dev, monkeypatch, name, dt, tol_logits, tol_grad):
+    """SURVEY §8a S5 (cambrian_arch.py:382-402): two query groups, the second with query_side_len 2 != the final 4 x 4
+    grid -> its sampler runs on 2 x 2 queries over larger windows, its output is bilinearly resized to 4 x 4 and
+    channel-concatenated in front of mm_projector (1024 * 2 inputs).  Forward, loss and every gradient vs the oracle."""
+    from cambrian_amd.train.data_layout import synthetic_batch
+    model, cfg, towers = _build(dev, dt, monkeypatch, query_nums=[SIDE * SIDE, 4])
+    assert model.model.vision_query.shape == (2, VH) and model.model.state_dict()["mm_projector.0.weight"].shape[1] == 2 * VH
+    assert [tuple(l.kv_size_list) for l in (model.model.vision_sampler_0.layers[0], model.model.vision_sampler_1.layers[0])] \
+        == [(1, 2), (2, 4)]
+    batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
+                            image_res=[56, 64], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
+    _compare(dev, dt, model, cfg, towers, batch, tol_logits, tol_grad, min_checked=60)
 
 
 @pytest.mark.parametrize("lm,nkv,window", [("llama", 4, None), ("phi3", 4, None), ("phi3", 4, 16)])

@@ -32,6 +32,33 @@ def test_sva_oracle_matches_reference_forward_and_backward():
         assert torch.allclose(p[name].grad, g, atol=2e-5, rtol=1e-4), name
 
 
+@pytest.mark.parametrize("q_dim", [1024, 4096])
+def test_sva_oracle_matches_reference_at_kernel_dims(q_dim):
+    """sva_k1024.pt: the real vision_sampler.py at the dimensions the HIP kernels run (hidden 1024, windows [1,1,1,4]);
+    weights and inputs are regenerated from the fixture's seed (tests/golden_recipes.py)."""
+    from golden_recipes import fill_state, grad_summary, sva_k1024_inputs
+    from oracle import sva
+    fx = _load("sva_k1024.pt")[q_dim]
+    c = fx["cfg"]
+    shapes = sva.init_sampler_params(c["q_dim"], c["hidden"], [c["hidden"]] * 4, c["kv_sizes"], c["hidden"], 1,
+                                     torch.Generator().manual_seed(0))
+    p = {k: v.requires_grad_() for k, v in fill_state(shapes, c["seed"]).items()}
+    q, ctx, kvs, masks, w = sva_k1024_inputs(c["q_dim"], c["hidden"], c["kv_sizes"], c["qside"], c["B"], c["seed"])
+    q.requires_grad_(); ctx.requires_grad_()
+    kvs = [k.requires_grad_() for k in kvs]
+    out = sva.vision_token_sampler(p, q, ctx, kvs, masks)
+    assert torch.allclose(out, fx["out"], atol=1e-5, rtol=1e-4)
+    (out * w).sum().backward()
+    assert torch.allclose(q.grad, fx["dq"], atol=2e-5, rtol=1e-3)
+    assert torch.allclose(ctx.grad, fx["dctx"], atol=2e-5, rtol=1e-3)
+    for a, b in zip(kvs, fx["dkvs"]):
+        assert torch.allclose(a.grad, b, atol=2e-5, rtol=1e-3)
+    assert set(fx["dparams"]) == set(p)
+    for name, want in fx["dparams"].items():
+        got = grad_summary(p[name].grad, name, c["seed"])
+        assert torch.allclose(got, want, atol=1e-3 * float(want[1]) + 1e-5, rtol=0), name
+
+
 def test_sva_oracle_mask_size_check():
     from oracle import sva
     fx = _load("sva_small.pt")
@@ -128,12 +155,14 @@ class _NS:
         self.__dict__.update(kw)
 
 
-def test_arch_oracle_matches_reference_prepare_inputs():
-    """cambrian_arch.py:340-490 static branch, forward and gradients, plus the bit-exact window gather (:271-287)."""
+@pytest.mark.parametrize("fixture", ["arch_small.pt", "arch_groups_small.pt"])
+def test_arch_oracle_matches_reference_prepare_inputs(fixture):
+    """cambrian_arch.py:340-490 static branch, forward and gradients, plus the bit-exact window gather (:271-287);
+    arch_groups_small.pt: two query groups, the second resized from 2 x 2 to the final grid (:395-401, S5)."""
     from oracle import arch
-    fx = _load("arch_small.pt")
+    fx = _load(fixture)
     c = fx["cfg"]
-    cfg = _NS(image_token_len=c["side"] ** 2, query_num_list=[c["side"] ** 2])
+    cfg = _NS(image_token_len=c["side"] ** 2, query_num_list=c.get("query_nums", [c["side"] ** 2]))
     p = {k: v.clone().requires_grad_() for k, v in fx["state"].items()}
     feats = [f.clone().requires_grad_() for f in fx["feats"]]
     emb, kv_final, mask_final, ctx_final = arch.prepare_inputs_static(p, cfg, fx["ids"], feats, fx["aux_masks"],
