@@ -52,6 +52,17 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
                     "config 4's partitioning) instead of all-reduce + replicated AdamW")
+    ap.add_argument("--zero3", action="store_true", help="ZeRO-3 (BASELINE config 5's partitioning; XLA-FSDP full_shard in the "
+                    "reference): every decoder layer and every trainable SVA / projector module is a Zero3Unit — parameters "
+                    "sharded 1/world, all-gathered around each unit's forward and backward, gradients reduce-scattered")
+    ap.add_argument("--preset", choices=["8b", "13b", "34b"], default="8b",
+                    help="decoder geometry + in-LLM SVA placement: 8b = Llama-3-8B (the headline, BASELINE configs[2]); "
+                         "13b = Vicuna-13B (H 5120, 40 layers, 10 SVA layers stride 4, image_position 35: configs[3]); "
+                         "34b = Yi-34B (H 7168, 60 layers, 9 SVA layers stride 7, image_position 87: configs[4]).  Anything "
+                         "but 8b is not the headline line; combine with --llm-layers to fit / for quick runs (marked INVALID)")
+    ap.add_argument("--no-masked-case", action="store_true",
+                    help="skip the extra (not headline) steps on letter-boxed (336, 224) / (224, 336) images: real collator "
+                         "batches carry key-padding and SVA window masks (SURVEY.md §8d second case)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--fp8-projections", action="store_true",
                     help="BASELINE configs[4] mode: forward GEMMs of the KV-side SVA projections in fp8 (marks the line: "
@@ -67,11 +78,32 @@ def parse():
     return ap.parse_args()
 
 
-def build_model(dev, llm_layers=None):
+# decoder geometry and in-LLM SVA placement of the three release sizes (scripts/cambrian/pretrain_cambrian_{8b,13b,34b}.sh;
+# SURVEY.md §8d table).  head_dim is 128 for all three, so the flash kernels serve them unchanged.
+PRESETS = {
+    "8b": dict(llm={}, sva=dict(n=10, start=0, stride=3, image_position=91), name="Llama-3-8B"),
+    "13b": dict(llm=dict(vocab_size=32000, hidden_size=5120, intermediate_size=13824, num_hidden_layers=40,
+                         num_attention_heads=40, num_key_value_heads=40, rope_theta=10000.0, max_position_embeddings=4096),
+                sva=dict(n=10, start=0, stride=4, image_position=35), name="Vicuna-13B"),
+    "34b": dict(llm=dict(vocab_size=64000, hidden_size=7168, intermediate_size=20480, num_hidden_layers=60,
+                         num_attention_heads=56, num_key_value_heads=8, rope_theta=5000000.0, max_position_embeddings=4096),
+                sva=dict(n=9, start=0, stride=7, image_position=87), name="Yi-34B"),
+}
+
+
+def build_model(dev, llm_layers=None, preset="8b"):
     from cambrian_amd.model.language_model.cambrian_llama import (CambrianLlamaForCausalLM, apply_release_8b_vision_config,
                                                                 llama3_8b_config)
-    cfg = llama3_8b_config() if llm_layers is None else llama3_8b_config(num_hidden_layers=llm_layers)
+    geo = dict(PRESETS[preset]["llm"])
+    if llm_layers is not None:
+        geo["num_hidden_layers"] = llm_layers
+    cfg = llama3_8b_config(**geo)
     apply_release_8b_vision_config(cfg)
+    sva = PRESETS[preset]["sva"]
+    depth = cfg.num_hidden_layers
+    cfg.num_of_vision_sampler_layers = len([k for k in range(sva["n"]) if sva["start"] + k * sva["stride"] < depth])
+    cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers = sva["start"], sva["stride"]
+    cfg.image_position = sva["image_position"]
     cfg.fused_loss = True  # fp32 log-sum-exp over the bf16 logits, no logits.float() copy (same loss / gradients)
     torch.manual_seed(0)
     model = CambrianLlamaForCausalLM(cfg, device=dev, llm_dtype=torch.bfloat16)
@@ -124,6 +156,22 @@ def cpu_baseline():
                       f"{step_gflop:.0f} GFLOP/img (towers fwd + 3x SVA side)"}
 
 
+def reference_cpu_run():
+    """The reference's OWN modules timed on the build container's cores (tools/cpu_reference_baseline.py — the reference
+    tree does not exist on the GPU box, so that run cannot happen here): real VisionTokenSampler x 13, real
+    prepare_inputs_labels_for_multimodal, installed-HF towers at the release dimensions.  Reported beside the live port
+    sample above; kind "reference", cores as recorded in the file."""
+    path = os.path.join(ROOT, "profiles", "r02_cpu_reference_baseline.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return {"value": d["images_per_s"], "unit": "images/s (tower+SVA part of the step, B = 1, fp32)", "cores": d["cores"],
+                "kind": "reference", "host": d.get("host"), "sample": d["what"], "parts_s": d["parts"],
+                "source": "profiles/r02_cpu_reference_baseline.json (tools/cpu_reference_baseline.py, build container)"}
+    except Exception:
+        return None
+
+
 def pmc_note():
     path = os.path.join(ROOT, "profiles", "pmc_gemm256.json")
     try:
@@ -169,17 +217,32 @@ def main():
     from cambrian_amd.train.llm_gemm_tuning import load_tuned_llm_gemms
     tuned = args.tuned_llm_gemms and load_tuned_llm_gemms()
 
-    model, cfg = build_model(dev, args.llm_layers)
+    model, cfg = build_model(dev, args.llm_layers, args.preset)
     cfg.fp8_projections = bool(args.fp8_projections)
     params = [p for p in model.parameters() if p.requires_grad]
-    if args.zero2:
+    z3_units = None
+    if args.zero3:
+        # XLA-FSDP full_shard of the reference (fsdp_config.json): one unit per decoder layer (frozen: sharded for
+        # memory), one per trainable SVA / projector module; what does not belong to a unit (vision_query,
+        # image_newline, embeddings, final norm, lm_head) stays replicated and goes through GradSync
+        from cambrian_amd.train.zero3 import zero3_finalize, zero3_parameters, zero3_wrap
+        m = model.model
+        mods = list(m.layers) + list(m.vision_sampler_layers) + [m.vision_sampler_0, m.mm_projector] + \
+            [getattr(m, f"mm_projector_aux_{i}") for i in range(len(cfg.mm_vision_tower_aux_list))]
+        in_units = {id(p) for mod in mods for p in mod.parameters()}
+        z3_units = zero3_wrap(mods)
+        rest = [p for p in params if id(p) not in in_units]
+        opt = torch.optim.AdamW(zero3_parameters(z3_units) + rest, lr=1e-4, weight_decay=0.0, fused=True)
+        sync = GradSync(rest) if rest else None
+    elif args.zero2:
         from cambrian_amd.train.zero import Zero2AdamW
         opt, sync = Zero2AdamW(params, lr=1e-4, weight_decay=0.0), None
     else:
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
         sync = GradSync(params)
     B = args.batch
-    batch = synthetic_batch(B, seed=1234 + rank)
+    pos0 = cfg.image_position
+    batch = synthetic_batch(B, seed=1234 + rank, image_position=pos0)
     kw = dict(input_ids=batch["input_ids"].to(dev), labels=batch["labels"].to(dev),
               position_ids=batch["position_ids"].to(dev),
               attention_mask=None,  # square synthetic images: nothing is padded -> plain causal attention
@@ -200,11 +263,14 @@ def main():
                                    torch.bfloat16)
         feed = DevicePrefetcher(itertools.cycle(host), pre)
 
-    def step():
+    def step(kw_=None):
+        kw_ = kw if kw_ is None else kw_
         if feed is not None:
-            kw["images"] = next(feed)["images"]
-        out = model(**kw)
+            kw_["images"] = next(feed)["images"]
+        out = model(**kw_)
         out.loss.backward()
+        if z3_units is not None:
+            zero3_finalize(z3_units)
         if sync is not None:
             sync.finish()
         opt.step()
@@ -234,6 +300,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # second case (NOT the headline): letter-boxed images -> the collator's key-padding mask in the decoder attention and
+    # partially masked SVA windows.  Same step, same timing brackets, 2 steps.
+    masked = None
+    if not args.no_masked_case:
+        sizes = [(336, 224) if i % 2 == 0 else (224, 336) for i in range(B)]
+        mb = synthetic_batch(B, seed=4321 + rank, image_position=pos0, image_sizes=sizes)
+        mkw = dict(kw, input_ids=mb["input_ids"].to(dev), labels=mb["labels"].to(dev), position_ids=mb["position_ids"].to(dev),
+                   attention_mask=mb["attention_mask"].to(dev),
+                   image_aux_attention_masks_list=[m_.to(dev) for m_ in mb["image_aux_attention_masks_list"]],
+                   image_sizes=mb["image_sizes"])
+        step(mkw)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for _ in range(2):
+            step(mkw)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tm = torch.tensor([time.perf_counter() - tm], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        masked = {"image_sizes": "(336,224) / (224,336) alternating", "steps": 2, "ms_per_step": float(tm.item()) / 2 * 1e3,
+                  "images_per_s": B * world * 2 / float(tm.item()),
+                  "masked_key_fraction": float(1.0 - mb["attention_mask"].float().mean().item()),
+                  "vs_square_case": (float(tm.item()) / 2) / (elapsed / args.steps)}
+
     if rank == 0:
         line = {
             "metric": "train images/sec (fwd+bwd) Cambrian-8B 4-tower SVA, 576 vis-tok",
@@ -247,13 +341,20 @@ def main():
                                    "Llama-3-8B, 576 visual + 24 newline tokens in a 2048-token sequence, pre-training "
                                    "stage (SVA+projectors train, LLM+towers frozen), fwd+bwd+all-reduce+AdamW",
                        "images_per_gpu": B, "global_batch": B * world, "seq_len": 2048,
-                       "parallelism": f"dp{world}" + ("+zero2" if args.zero2 else ""), "loss": float(loss.item()),
+                       "parallelism": f"dp{world}" + ("+zero2" if args.zero2 else "") + ("+zero3" if args.zero3 else ""),
+                       "loss": float(loss.item()),
                        "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
                        "llm_gemm_solutions": "pre-tuned TunableOp table" if tuned else "PyTorch default heuristic"},
         }
         if args.fp8_projections:
             line["dtype"] = "bf16 + fp8 (e4m3, row-wise scales) forward GEMMs of the KV-side SVA projections"
             line["config"]["NOT_HEADLINE"] = "reduced-precision mode of BASELINE configs[4]; the headline line is the bf16 run"
+        if masked is not None:
+            line["masked_case"] = masked
+        if args.preset != "8b":
+            line["config"]["NOT_HEADLINE"] = (f"decoder preset {args.preset} ({PRESETS[args.preset]['name']}: BASELINE "
+                                              f"configs[{3 if args.preset == '13b' else 4}] geometry); the headline is 8b")
+            line["config"]["workload"] = line["config"]["workload"].replace("Llama-3-8B", PRESETS[args.preset]["name"])
         if args.llm_layers is not None:
             line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"
         if prof:
@@ -295,6 +396,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline()
+                ref_run = reference_cpu_run()
+                if ref_run is not None:
+                    line["cpu_baseline"]["reference_run"] = ref_run
             except Exception as e:  # the baseline must never take the measurement down
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(line), flush=True)

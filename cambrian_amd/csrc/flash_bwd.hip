@@ -37,7 +37,16 @@ struct FlashParams {
   int B, S, H, HKV;
   int kv_len;   // non-causal kernels: keys >= kv_len are padding (masked); S is kv_len rounded up to 128
   float scale;
+  // causal kernels: optional key-padding mask, [B, S] bytes, non-zero = the key may be attended to.  A query may see key k
+  // iff k <= q and (key_valid[b][k] or k == q): the collator's attention_mask (train_fsdp.py:1057-1085) AND the causal
+  // triangle, with the diagonal kept open so that a padded query row is never empty (its loss is ignored).
+  const uint8_t* key_valid;
 };
+
+// validity bits of the 64 keys of tile t (lane i contributes key 64 t + i); all ones without a mask
+__device__ __forceinline__ uint8_t kv_byte(const FlashParams& p, int b, int t, int lane) {
+  return p.key_valid ? p.key_valid[(int64_t)b * p.S + t * 64 + lane] : (uint8_t)1;
+}
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -133,16 +142,20 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
   TileRegs rk, rv;
   tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
   tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
+  uint8_t vb = CAUSAL ? kv_byte(p, b, 0, lane) : (uint8_t)1;  // key-padding byte of this lane's key of the NEXT tile
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // previous tile consumed
     tile_put<true, false>(rk, sK, nullptr, tid);
     tile_put<false, true>(rv, nullptr, sVT, tid);
     __syncthreads();
+    const uint64_t vw = CAUSAL ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;  // validity of this tile's 64 keys
     if (t + 1 < nt) {  // the next tile's loads fly during this tile's MFMAs
       tile_load(rk, kbase, p.kv_ss, (t + 1) * 64, p.S, tid);
       tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
+      if (CAUSAL) vb = kv_byte(p, b, t + 1, lane);
     }
     if (CAUSAL && t * 64 > q0 + 31) continue;
+    if (CAUSAL && vw == 0 && t * 64 + 63 < q0) continue;  // a tile of padding below the wave's diagonal: nothing to add
     f32x16_t s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -166,6 +179,17 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
           const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
           if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[kt][r] = -INFINITY;
         }
+    }
+    if (CAUSAL && vw != ~0ull) {  // a tile with padded keys (wave-uniform: most tiles skip this)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const uint32_t w = (uint32_t)(vw >> (kt * 32)) >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (!((w >> ((r & 3) + 8 * (r >> 2))) & 1u) && key != qi) s[kt][r] = -INFINITY;
+        }
+      }
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -282,16 +306,20 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
   TileRegs rk, rv;
   tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
   tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
+  uint8_t vb = CAUSAL ? kv_byte(p, b, 0, lane) : (uint8_t)1;
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // previous tile fully consumed
     tile_put<true, true>(rk, sK, sKT, tid);
     tile_put<true, false>(rv, sV, nullptr, tid);
     __syncthreads();
+    const uint64_t vw = CAUSAL ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
     if (t + 1 < nt) {  // the next tile's loads fly during this tile's MFMAs
       tile_load(rk, kbase, p.kv_ss, (t + 1) * 64, p.S, tid);
       tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
+      if (CAUSAL) vb = kv_byte(p, b, t + 1, lane);
     }
     if (CAUSAL && t * 64 > q0 + 31) continue;  // whole tile above this wave's diagonal (block-uniform barriers stay matched)
+    if (CAUSAL && vw == 0 && t * 64 + 63 < q0) continue;  // padding only, below the diagonal
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16_t s, dp;
@@ -310,6 +338,14 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
         for (int r = 0; r < 16; ++r) {
           const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
           if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[r] = -INFINITY;   // exp2(-inf) = 0
+        }
+      }
+      if (CAUSAL && vw != ~0ull) {  // padded keys in this tile
+        const uint32_t w = (uint32_t)(vw >> (kt * 32)) >> (4 * g);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (!((w >> ((r & 3) + 8 * (r >> 2))) & 1u) && key != qi) s[r] = -INFINITY;
         }
       }
 #pragma unroll
@@ -384,6 +420,9 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
     vf[ks] = *reinterpret_cast<const bf16x8_t*>(vrow + ks * 16 + g * 8);
   }
   const float c2 = p.scale * LOG2E;
+  // key-padding mask: this lane's key is padded -> only its own query (the open diagonal) contributes
+  const bool kvalid = !CAUSAL || !p.key_valid || p.key_valid[(int64_t)b * p.S + ki] != 0;
+  const bool wave_padded = __builtin_amdgcn_ballot_w64(!kvalid) != 0;
   f32x16_t adk[DT], adv[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d)
@@ -460,7 +499,7 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
         }
         f32x16_t pr;
         // mask only where some key of the wave can be masked for some query of this 32-row half tile
-        const bool edge = CAUSAL ? (k0 + 31 > qt * 64 + qs * 32) : (k0 + 32 > p.kv_len);
+        const bool edge = (CAUSAL ? (k0 + 31 > qt * 64 + qs * 32) : (k0 + 32 > p.kv_len)) || wave_padded;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int qrow = qs * 32 + 8 * r4 + 4 * g;  // rows qrow .. qrow+3 <-> registers 4*r4 .. 4*r4+3
@@ -472,7 +511,7 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
             float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -l4[e]));
             if (edge) {
               const int qidx = qt * 64 + qrow + e;
-              if (!(CAUSAL ? ki <= qidx : ki < p.kv_len)) pv = 0.f;
+              if (!(CAUSAL ? (ki <= qidx && (kvalid || ki == qidx)) : ki < p.kv_len)) pv = 0.f;
             }
             pr[r] = pv;
             s[r] = pv * (dp[r] - d4[e]);  // dS
@@ -526,8 +565,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
 extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                                   const float* lse, int64_t B, int64_t S, int32_t H, int32_t HKV, int32_t hd,
                                   int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
-                                  float scale, int32_t causal, int64_t kv_len, float* dvec, void* dq, void* dk, void* dv,
-                                  void* stream) {
+                                  float scale, int32_t causal, int64_t kv_len, const uint8_t* key_valid, float* dvec,
+                                  void* dq, void* dk, void* dv, void* stream) {
   if (!q || !k || !v || !o || !dout || !lse || !dvec || !dq || !dk || !dv) return CMB_ERR_BAD_ARG;
   if (hd != HD || S <= 0 || (S % 128) != 0 || H <= 0 || HKV <= 0 || (H % HKV) != 0 || B < 0) return CMB_ERR_SHAPE;
   if (!causal && (kv_len <= 0 || kv_len > S)) return CMB_ERR_SHAPE;
@@ -539,6 +578,7 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   p.lse = lse; p.dvec = dvec;
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
+  p.key_valid = causal ? key_valid : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const int64_t nkb = S / 128;
   const int items = flash_items((int)nkb, causal != 0);
@@ -566,8 +606,8 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
 
 extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t B, int64_t S, int32_t H, int32_t HKV,
                                   int32_t hd, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss,
-                                  int64_t kv_sh, float scale, int32_t causal, int64_t kv_len, void* out, float* lse,
-                                  void* stream) {
+                                  int64_t kv_sh, float scale, int32_t causal, int64_t kv_len, const uint8_t* key_valid,
+                                  void* out, float* lse, void* stream) {
   if (!q || !k || !v || !out || !lse) return CMB_ERR_BAD_ARG;
   if (hd != HD || S <= 0 || (S % 128) != 0 || H <= 0 || HKV <= 0 || (H % HKV) != 0 || B < 0) return CMB_ERR_SHAPE;
   if (!causal && (kv_len <= 0 || kv_len > S)) return CMB_ERR_SHAPE;
@@ -578,6 +618,7 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.dq = p.dk = p.dv = nullptr; p.lse = nullptr; p.dvec = nullptr;
   p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh; p.kv_sb = kv_sb; p.kv_ss = kv_ss; p.kv_sh = kv_sh;
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
+  p.key_valid = causal ? key_valid : nullptr;
   const int64_t nqb = S / 128;
   const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal != 0) * H * B));   // 1-D: flash_map.h
   if (causal)

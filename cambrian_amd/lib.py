@@ -120,9 +120,9 @@ SIGNATURES = {
     "cmb_cross_entropy_bwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p, _p, _p, _i64, _p]),
     "cmb_qkv_rope": (C.c_int, [C.c_int, _i32, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _p, _p, _p, _p]),
     "cmb_flash_attn_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f, _i32, _i64,
-                                     _p, _p, _p]),
+                                     _p, _p, _p, _p]),
     "cmb_flash_attn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _f,
-                                     _i32, _i64, _p, _p, _p, _p, _p]),
+                                     _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "cmb_swiglu_bwd": (C.c_int, [C.c_int, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p]),
     "cmb_resize_coeffs": (C.c_int, [_i32, _i32, _p, _p]),
     "cmb_image_preprocess": (C.c_int, [_p, _p, _i32, _p, _p, _p, _p, _i32, _p, _p, _p]),

@@ -71,6 +71,8 @@ def _fused_frozen_weight(owner: nn.Module, key: str, mods) -> Optional[torch.Ten
     ws = [m.weight for m in mods]
     if any(w.requires_grad for w in ws) or any(m.bias is not None for m in mods):
         return None
+    if getattr(owner, "_cmb_no_weight_cache", False):
+        return None  # ZeRO-3 unit: a cached concatenation would keep the whole layer resident on every rank
     tag = tuple((w.data_ptr(), w._version, w.dtype) for w in ws)
     cached = owner.__dict__.get(key)
     if cached is None or cached[0] != tag:
@@ -113,7 +115,8 @@ def _frozen_transposed(owner: nn.Module, key: str, w: torch.Tensor) -> torch.Ten
 
 def frozen_linear(owner: nn.Module, key: str, x: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None):
     """``F.linear(x, w)`` (+ residual); frozen bias-free GPU weights take FrozenLinearFn, anything else the stock path."""
-    if w.requires_grad or not x.is_cuda:
+    if w.requires_grad or not x.is_cuda or getattr(owner, "_cmb_no_weight_cache", False):
+        # (ZeRO-3 units: no transposed copy either — the layer's storage is dropped between its uses, zero3.py)
         y = F.linear(x, w)
         return y if residual is None else residual + y
     x2 = x.reshape(-1, x.shape[-1])
@@ -158,6 +161,26 @@ class LlamaMLP(nn.Module):
         return _down_proj(self.down_proj, inner, residual)
 
 
+class KeyPadding:
+    """The decoder's attention mask when it is "causal AND key-padding, diagonal open" (every collator batch without a
+    sliding window): carried as the [B, S] key mask so the HIP flash kernels can apply it tile by tile; ``dense()`` builds
+    the [B, 1, S, S] boolean mask for the stock kernel (what the reference's HF decoder materialises,
+    cambrian_llama.py:142-166)."""
+
+    def __init__(self, key_valid: torch.Tensor):
+        self.key_valid = key_valid.to(torch.bool)
+        self._dense = None
+
+    def dense(self) -> torch.Tensor:
+        if self._dense is None:
+            B, S = self.key_valid.shape
+            dev = self.key_valid.device
+            m = torch.ones(S, S, dtype=torch.bool, device=dev).tril_()[None, None] & self.key_valid[:, None, None, :]
+            # a fully masked query row would be NaN in SDPA; padded rows attend to themselves (their loss is ignored)
+            self._dense = m | torch.eye(S, dtype=torch.bool, device=dev)[None, None]
+        return self._dense
+
+
 class LlamaAttention(nn.Module):
     def __init__(self, cfg, device, dtype):
         super().__init__()
@@ -177,12 +200,20 @@ class LlamaAttention(nn.Module):
             q, k, v = ops.qkv_rope(frozen_linear(self, "_w_qkv_t", x, w_qkv), cos, sin, self.nh, self.nkv, self.hd)
             if kv_out is not None:
                 kv_out.append((k, v))
-            if attn_mask is None and torch.is_grad_enabled() and q.requires_grad and ops.causal_attention_supported(q, k):
-                o = ops.causal_attention(q, k, v)  # stock flash forward, HIP backward (flash_bwd.hip)
+            # attn_mask is None (plain causal) or a KeyPadding marker (causal AND the collator's key mask, diagonal open):
+            # both run on flash_bwd.hip; only a dense mask (sliding window) falls through to the stock kernel
+            key_valid = attn_mask.key_valid if isinstance(attn_mask, KeyPadding) else None
+            if (attn_mask is None or key_valid is not None) and torch.is_grad_enabled() and q.requires_grad \
+                    and ops.causal_attention_supported(q, k):
+                o = ops.causal_attention(q, k, v, key_valid)
             else:
+                if key_valid is not None:
+                    attn_mask = attn_mask.dense()
                 o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                                    enable_gqa=self.nkv != self.nh)
             return _lin(self.o_proj, o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
+        if isinstance(attn_mask, KeyPadding):
+            attn_mask = attn_mask.dense()
         q = ops.rope(self.q_proj(x).view(B * S, self.nh, self.hd), cos, sin).view(B, S, self.nh, self.hd).transpose(1, 2)
         k = ops.rope(self.k_proj(x).view(B * S, self.nkv, self.hd), cos, sin).view(B, S, self.nkv, self.hd).transpose(1, 2)
         v = self.v_proj(x).view(B, S, self.nkv, self.hd).transpose(1, 2)
@@ -270,7 +301,9 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
         window = getattr(cfg, "sliding_window", None)
         if window is not None and S <= window + 1:
             window = None                      # every key is within reach: plain causal attention
-        if attention_mask is not None or window is not None:
+        if attention_mask is not None and window is None:
+            attn_mask = KeyPadding(attention_mask)
+        elif attention_mask is not None or window is not None:
             causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril_()
             if window is not None:             # Phi-3 eager mask (phi3/modeling_phi3.py:1180-1186): 0 <= i - j <= window
                 causal = causal & ~torch.ones(S, S, dtype=torch.bool, device=dev).tril_(-(window + 1))

@@ -79,9 +79,14 @@ class Phi3Attention(nn.Module):
         q, k, v = ops.qkv_rope(_lin(self.qkv_proj, x).contiguous(), cos, sin, self.nh, self.nkv, self.hd)
         if kv_out is not None:
             kv_out.append((k, v))
-        if attn_mask is None and torch.is_grad_enabled() and q.requires_grad and ops.causal_attention_supported(q, k):
-            o = ops.causal_attention(q, k, v)             # head_dim 128 geometries (Phi-3-medium); mini is 96 -> SDPA
+        from .cambrian_llama import KeyPadding
+        key_valid = attn_mask.key_valid if isinstance(attn_mask, KeyPadding) else None
+        if (attn_mask is None or key_valid is not None) and torch.is_grad_enabled() and q.requires_grad \
+                and ops.causal_attention_supported(q, k):
+            o = ops.causal_attention(q, k, v, key_valid)  # head_dim 128 geometries (Phi-3-medium); mini is 96 -> SDPA
         else:
+            if key_valid is not None:
+                attn_mask = attn_mask.dense()
             o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                                enable_gqa=self.nkv != self.nh)
         return _lin(self.o_proj, o.transpose(1, 2).reshape(B, S, self.nh * self.hd))

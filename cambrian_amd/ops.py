@@ -1027,11 +1027,12 @@ class CausalAttnFn(torch.autograd.Function):
     backward = dQ kernel + dK/dV kernel (no atomics).  K/V are read un-expanded (grouped heads): no
     repeat_interleave copies of K and V per layer as F.scaled_dot_product_attention(enable_gqa=True) makes.
     ``kv_len`` None: causal (the decoder).  ``kv_len`` = n: bidirectional over keys [0, n), rows [n, S) are padding
-    (trainable vision towers, see ``vit_attention``)."""
+    (trainable vision towers, see ``vit_attention``).  ``key_valid`` (causal only): uint8 / bool [B, S] key-padding mask of
+    the collator; query q sees key k iff k <= q and (key_valid[b, k] or k == q)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale=None, kv_len=None):
-        L.require_gpu(q, k, v)
+    def forward(ctx, q, k, v, scale=None, kv_len=None, key_valid=None):
+        L.require_gpu(q, k, v, key_valid)
         B, H, S, D = q.shape
         HKV = k.shape[1]
         scale = 1.0 / math.sqrt(D) if scale is None else float(scale)
@@ -1039,12 +1040,18 @@ class CausalAttnFn(torch.autograd.Function):
         q, k, v = _token_major(q), _token_major(k), _token_major(v)
         out = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+        if key_valid is not None:
+            if not causal or key_valid.shape != (B, S):
+                raise L.CambrianAmdError("key_valid is a [B, S] mask of the causal form")
+            key_valid = key_valid.view(torch.uint8) if key_valid.dtype == torch.bool else key_valid.to(torch.uint8)
+            key_valid = key_valid.contiguous()
         rc = L.load().cmb_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), B, S, H, HKV, D, S * H * D, H * D, D,
-                                         S * HKV * D, HKV * D, D, scale, causal, n, out.data_ptr(), lse.data_ptr(),
-                                         L.stream_ptr(q.device))
+                                         S * HKV * D, HKV * D, D, scale, causal, n, L.ptr(key_valid), out.data_ptr(),
+                                         lse.data_ptr(), L.stream_ptr(q.device))
         L.check(rc, "cmb_flash_attn_fwd")
         out = out.transpose(1, 2)  # [B,H,S,D] view of token-major storage: the o_proj input needs no copy
         ctx.save_for_backward(q, k, v, out, lse)
+        ctx.key_valid = key_valid
         ctx.cfg = (scale, causal, n)
         return out
 
@@ -1063,10 +1070,10 @@ class CausalAttnFn(torch.autograd.Function):
         lse = lse.contiguous()
         rc = L.load().cmb_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                          lse.data_ptr(), B, S, H, HKV, D, S * H * D, H * D, D, S * HKV * D, HKV * D, D,
-                                         scale, causal, n, dvec.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                         L.stream_ptr(q.device))
+                                         scale, causal, n, L.ptr(ctx.key_valid), dvec.data_ptr(), dq.data_ptr(),
+                                         dk.data_ptr(), dv.data_ptr(), L.stream_ptr(q.device))
         L.check(rc, "cmb_flash_attn_bwd")
-        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None, None
+        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None, None, None
 
 
 def vit_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
@@ -1088,9 +1095,10 @@ def causal_attention_supported(q: torch.Tensor, k: torch.Tensor) -> bool:
             and q.shape[2] == k.shape[2] and q.shape[1] % k.shape[1] == 0)
 
 
-def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
-    """q [B,H,S,128], k / v [B,HKV,S,128] (any strides with a contiguous last dim) -> [B,H,S,128]."""
-    return CausalAttnFn.apply(q, k, v)
+def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B,H,S,128], k / v [B,HKV,S,128] (any strides with a contiguous last dim) -> [B,H,S,128].  ``key_valid``: optional
+    bool / uint8 [B,S] key-padding mask (the collator's ``attention_mask``); the diagonal stays open."""
+    return CausalAttnFn.apply(q, k, v, None, None, key_valid)
 
 
 class AddRmsNormFn(torch.autograd.Function):

@@ -34,6 +34,13 @@ class Zero3Unit:
         self.params: List[nn.Parameter] = [p for p in module.parameters()]
         if not self.params:
             raise ValueError("Zero3Unit needs a module with parameters")
+        # the decoder blocks cache fused / transposed copies of FROZEN weights on their sub-modules
+        # (cambrian_llama.py::_fused_frozen_weight, _frozen_transposed): under ZeRO-3 those copies would stay resident
+        # after release() and undo the sharding, so sharded modules opt out of them
+        for sub in module.modules():
+            sub.__dict__["_cmb_no_weight_cache"] = True
+            for k in [k for k in sub.__dict__ if k.startswith("_w_")]:
+                del sub.__dict__[k]
         dev, dt = self.params[0].device, self.params[0].dtype
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("all parameters of a Zero3Unit must share device and dtype")
@@ -110,6 +117,16 @@ class Zero3Unit:
         self.shard.grad = g if self.shard.grad is None else self.shard.grad + g
         self.release()
 
+    def finalize(self) -> None:
+        """After backward(), before optimizer.step(): a trainable unit some of whose parameters received no gradient in
+        this step (unused branch) never counts down to zero in ``_on_grad`` — reduce what arrived (missing gradients
+        enter the collective as zeros, every rank calls this, so the collectives stay matched) and drop the storage."""
+        if self.trainable and self._pending > 0:
+            self._pending = 0
+            self._reduce_grads()
+        elif self._resident:
+            self.release()
+
     def full_state(self) -> List[torch.Tensor]:
         """Every parameter, materialised (for checkpointing / tests)."""
         self.gather()
@@ -120,6 +137,12 @@ class Zero3Unit:
 
 def zero3_wrap(modules: Iterable[nn.Module], process_group: Optional[dist.ProcessGroup] = None) -> List[Zero3Unit]:
     return [Zero3Unit(m, process_group) for m in modules]
+
+
+def zero3_finalize(units: Iterable[Zero3Unit]) -> None:
+    """Call between ``loss.backward()`` and ``optimizer.step()`` (see Zero3Unit.finalize)."""
+    for u in units:
+        u.finalize()
 
 
 def zero3_parameters(units: Iterable[Zero3Unit]) -> List[nn.Parameter]:

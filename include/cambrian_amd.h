@@ -92,7 +92,9 @@ typedef struct cmb_gemm_desc {
   int32_t split_k;
   void* workspace; int64_t workspace_bytes;
   int32_t tile_hint;       /* 0 = choose by grid-fill cost model; 128 / 256 = force that block tile (bf16 only);
-                              2560 / 2561 = 256 tile with schedule 0 (8-phase ping-pong, default) / 1 (in-wave pipeline) */
+                              2560 / 2561 = 256 tile with schedule 0 (8-phase ping-pong, default) / 1 (in-wave pipeline);
+                              2570 = persistent 4-wave 256x256 kernel, 2580 = persistent 256x128 kernel with two workgroups
+                              per CU (gemm_p4.hip; opt-in experimental configurations, same results) */
   const float* a_scale;    /* CMB_FP8_E4M3 only: [M] fp32 dequantisation factor of each A row (or NULL = 1) */
   const float* b_scale;    /* CMB_FP8_E4M3 only: [N] fp32 dequantisation factor of each B row (or NULL = 1);
                               the accumulator is multiplied by a_scale[m] * b_scale[n] before alpha / bias */
@@ -314,14 +316,20 @@ int cmb_qkv_rope(int dtype, int32_t merge, void* packed, const float* cos_t, con
  * causal == 0 is the bidirectional form used when the vision towers train (HF CLIPAttention /
  * Dinov2SelfAttention / timm Attention reached from clip_encoder.py:104, dino_encoder.py:159, siglip_encoder.py:97):
  * every query sees keys [0, kv_len); rows [kv_len, S) are padding (S = kv_len rounded up to 128, zero-filled by the
- * caller, head_dim zero-padded to 128) whose outputs / gradients are don't-care / zero. */
+ * caller, head_dim zero-padded to 128) whose outputs / gradients are don't-care / zero.
+ * key_valid (causal only; may be NULL): the collator's key-padding mask (train_fsdp.py:1057-1085, 1089-1165 — padded rows /
+ * columns of the 24 x 25 visual span, padded sequence tail), [B, S] bytes, non-zero = attendable.  Query q sees key k iff
+ * k <= q and (key_valid[b][k] or k == q): HF's causal AND padding mask (cambrian_llama.py:142-166) with the diagonal
+ * kept open so a padded query row is never empty.  Tiles made of padding only are skipped. */
 int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t B, int64_t S, int32_t H, int32_t HKV,
                        int32_t hd, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
-                       float scale, int32_t causal, int64_t kv_len, void* out, float* lse, void* stream);
+                       float scale, int32_t causal, int64_t kv_len, const uint8_t* key_valid, void* out, float* lse,
+                       void* stream);
 int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                        int64_t B, int64_t S, int32_t H, int32_t HKV, int32_t hd,
                        int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t kv_sb, int64_t kv_ss, int64_t kv_sh,
-                       float scale, int32_t causal, int64_t kv_len, float* dvec, void* dq, void* dk, void* dv, void* stream);
+                       float scale, int32_t causal, int64_t kv_len, const uint8_t* key_valid, float* dvec, void* dq, void* dk,
+                       void* dv, void* stream);
 /* Backward of h = silu(g) * u (Llama MLP gate; forward is cmb_act_mul with CMB_ACT_SILU):
  * dg = dh * u * silu'(g), du = dh * silu(g); all [rows, D] with row strides. */
 int cmb_swiglu_bwd(int dtype, const void* dh, int64_t lddh, const void* g, int64_t ldg, const void* u, int64_t ldu,

@@ -52,6 +52,85 @@ def test_flash_bwd_matches_fp32_autograd(dev, B, S, H, HKV):
     assert torch.equal(q2.grad, q.grad) and torch.equal(k2.grad, k.grad) and torch.equal(v2.grad, v.grad)
 
 
+def _collator_key_mask(B, S, image_sizes, position=91):
+    """attention_mask of real collator batches (train_fsdp.py:1089-1165): padded rows / columns of the 24 x 25 visual span
+    switched off, a padded tail on the last sample."""
+    from cambrian_amd.train.data_layout import prepare_image_info
+    m = torch.ones(B, S, dtype=torch.bool)
+    for b, size in enumerate(image_sizes):
+        vis, _ = prepare_image_info(size, 576, newline=True)          # bool [600]
+        if position + 600 <= S:
+            m[b, position:position + 600] = vis
+    m[B - 1, S - 137:] = False
+    return m
+
+
+@pytest.mark.parametrize("B,S,H,HKV", [(2, 1024, 8, 2), (3, 2048, 32, 8)])
+def test_flash_key_padding_mask_matches_fp32_autograd(dev, B, S, H, HKV):
+    """causal AND key-padding (diagonal open), forward + backward, against fp32 SDPA-by-hand with the dense mask the
+    reference's HF decoder materialises (cambrian_llama.py:142-166); masks from the collator's layout code for
+    non-square images, plus a mask with whole 64-key tiles of padding (tile skipping) and an all-valid one."""
+    from cambrian_amd import ops
+    g_ = torch.Generator().manual_seed(S + H + 1)
+    D, grp = 128, H // HKV
+    sizes = [(336, 224), (224, 336), (1000, 90)][:B]
+    masks = [_collator_key_mask(B, S, sizes), torch.ones(B, S, dtype=torch.bool)]
+    holes = torch.ones(B, S, dtype=torch.bool)
+    holes[0, 128:448] = False            # five whole key tiles of padding
+    holes[1, :70] = False                # the sequence starts with padding (rows that see only themselves)
+    masks.append(holes)
+    qs = torch.randn(B, S, H, D, generator=g_).to(torch.bfloat16).to(dev)
+    ks = torch.randn(B, S, HKV, D, generator=g_).to(torch.bfloat16).to(dev)
+    vs = torch.randn(B, S, HKV, D, generator=g_).to(torch.bfloat16).to(dev)
+    w = torch.randn(B, H, S, D, generator=g_).to(dev)
+    for kvmask in masks:
+        q, k, v = (t.transpose(1, 2).detach().requires_grad_() for t in (qs, ks, vs))
+        out = ops.causal_attention(q, k, v, kvmask.to(dev))
+        qr, kr, vr = (t.transpose(1, 2).detach().float().requires_grad_() for t in (qs, ks, vs))
+        dense = (torch.ones(S, S, dtype=torch.bool, device=dev).tril_()[None, None] & kvmask.to(dev)[:, None, None, :]) \
+            | torch.eye(S, dtype=torch.bool, device=dev)[None, None]
+        sc = qr @ kr.repeat_interleave(grp, 1).transpose(-1, -2) / math.sqrt(D)
+        ref = torch.softmax(sc.masked_fill(~dense, float("-inf")), -1) @ vr.repeat_interleave(grp, 1)
+        assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < 2e-2
+        (out.float() * w).sum().backward()
+        (ref * w).sum().backward()
+        for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+            err = ((a.float() - b).abs().max() / b.abs().max()).item()
+            assert err < 3e-2, f"{name}: rel err {err}"
+        if not kvmask.all():             # a padded key receives gradient only from its own (ignored) query row
+            pad = ~kvmask.to(dev)
+            assert torch.isfinite(k.grad.float()).all() and torch.isfinite(out.float()).all()
+            only_diag = (kr.grad.transpose(1, 2)[pad].abs().max() / kr.grad.abs().max()).item()
+            assert ((k.grad.float().transpose(1, 2)[pad] - kr.grad.transpose(1, 2)[pad]).abs().max().item()
+                    <= 3e-2 * kr.grad.abs().max().item()), only_diag
+
+
+def test_decoder_uses_hip_attention_for_collator_masks(dev, monkeypatch):
+    """a real collator batch (non-trivial attention_mask) must stay on flash_bwd.hip in training mode —
+    F.scaled_dot_product_attention is never reached."""
+    import torch.nn.functional as F
+    from cambrian_amd.model.language_model import cambrian_llama as CL
+    cfg = CL.CambrianConfig(vocab_size=512, hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                            num_attention_heads=4, num_key_value_heads=2, rms_norm_eps=1e-5, max_position_embeddings=2048,
+                            rope_theta=500000.0)
+    torch.manual_seed(0)
+    model = CL.LlamaBackbone(cfg, dev, torch.bfloat16)
+    B, S = 2, 1024
+    x = torch.randn(B, S, 512, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    mask = _collator_key_mask(B, S, [(336, 224), (224, 336)]).to(dev)
+
+    def boom(*a, **k):
+        raise AssertionError("stock SDPA reached with a key-padding mask")
+
+    cos, sin = __import__("cambrian_amd").ops.rope_table(torch.arange(S, device=dev)[None].expand(B, S), 128, 500000.0)
+    ref = model.layers[0].self_attn(x, cos, sin, CL.KeyPadding(mask).dense())          # stock path, dense mask
+    monkeypatch.setattr(F, "scaled_dot_product_attention", boom)
+    out = model.layers[0].self_attn(x, cos, sin, CL.KeyPadding(mask))
+    assert ((out.float() - ref.float()).abs().max() / ref.float().abs().max()).item() < 2e-2
+    out.float().sum().backward()
+    assert torch.isfinite(x.grad.float()).all()
+
+
 def test_flash_bwd_speed_vs_stock(dev):
     """Not an assertion on speed (printed for the log): backward time of the HIP kernels vs PyTorch's SDPA backward."""
     from cambrian_amd import ops

@@ -112,3 +112,52 @@ def test_zero3_single_process():
     for u, b in zip(units, ref):
         for a, w in zip(u.full_state(), b.parameters()):
             assert torch.allclose(a, w, atol=1e-7, rtol=1e-6)
+
+
+def test_zero3_finalize_flushes_units_with_unused_parameters():
+    """A trainable unit one of whose parameters gets no gradient never counts down in the hooks: ``zero3_finalize``
+    reduces what arrived (the missing gradient as zeros) and drops the full storage (zero3.py)."""
+    from cambrian_amd.train.zero3 import zero3_finalize, zero3_parameters, zero3_wrap
+
+    class TwoBranch(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.used = torch.nn.Linear(8, 8)
+            self.unused = torch.nn.Linear(8, 8)
+
+        def forward(self, x):
+            return self.used(x)
+
+    torch.manual_seed(0)
+    m = TwoBranch()
+    ref = [p.detach().clone() for p in m.parameters()]
+    (u,) = zero3_wrap([m])
+    x = torch.randn(4, 8)
+    m(x).pow(2).mean().backward()
+    assert u.shard.grad is None and u.resident            # stuck: the hooks wait for `unused`
+    zero3_finalize([u])
+    assert not u.resident and u.shard.grad is not None
+    g = u.shard.grad
+    n_used = ref[0].numel() + ref[1].numel()
+    assert g[:n_used].abs().sum() > 0 and torch.count_nonzero(g[n_used:]) == 0
+    assert zero3_parameters([u])[0] is u.shard
+
+
+def test_zero3_units_opt_out_of_frozen_weight_caches():
+    """cambrian_llama.py caches fused / transposed copies of frozen weights on the owning module; a ZeRO-3 unit must
+    not (they would keep the whole layer resident on every rank after release())."""
+    from cambrian_amd.model.language_model import cambrian_llama as CL
+    from cambrian_amd.train.zero3 import zero3_wrap
+    cfg = CL.CambrianConfig(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
+                            num_attention_heads=2, num_key_value_heads=2, rms_norm_eps=1e-5, max_position_embeddings=64,
+                            rope_theta=10000.0)
+    layer = CL.LlamaDecoderLayer(cfg, None, torch.float32)
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    att = layer.self_attn
+    assert CL._fused_frozen_weight(att, "_w_qkv", (att.q_proj, att.k_proj, att.v_proj)) is not None
+    assert "_w_qkv" in att.__dict__
+    zero3_wrap([layer])
+    assert "_w_qkv" not in att.__dict__                                      # dropped at wrap time
+    assert CL._fused_frozen_weight(att, "_w_qkv", (att.q_proj, att.k_proj, att.v_proj)) is None
+    assert all(m.__dict__.get("_cmb_no_weight_cache") for m in layer.modules())
