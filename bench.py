@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+os.environ.setdefault("CAMBRIAN_AMD_RANDOM_INIT", "1")  # random-init weights of the named architecture (no checkpoints offline)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md)
 
 # forward GFLOP per image of the release-8B path (BASELINE.md §2 / SURVEY.md §8d)
@@ -53,8 +54,8 @@ def parse():
     ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
                     "config 4's partitioning) instead of all-reduce + replicated AdamW")
     ap.add_argument("--zero3", action="store_true", help="ZeRO-3 (BASELINE config 5's partitioning; XLA-FSDP full_shard in the "
-                    "reference): every decoder layer and every trainable SVA / projector module is a Zero3Unit — parameters "
-                    "sharded 1/world, all-gathered around each unit's forward and backward, gradients reduce-scattered")
+                    "reference): every decoder layer is a Zero3Unit — parameters sharded 1/world, all-gathered around the "
+                    "layer's forward and backward; the SVA / projector parameters stay replicated (GradSync)")
     ap.add_argument("--preset", choices=["8b", "13b", "34b"], default="8b",
                     help="decoder geometry + in-LLM SVA placement: 8b = Llama-3-8B (the headline, BASELINE configs[2]); "
                          "13b = Vicuna-13B (H 5120, 40 layers, 10 SVA layers stride 4, image_position 35: configs[3]); "
@@ -222,13 +223,14 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     z3_units = None
     if args.zero3:
-        # XLA-FSDP full_shard of the reference (fsdp_config.json): one unit per decoder layer (frozen: sharded for
-        # memory), one per trainable SVA / projector module; what does not belong to a unit (vision_query,
-        # image_newline, embeddings, final norm, lm_head) stays replicated and goes through GradSync
+        # XLA-FSDP full_shard of the reference (fsdp_config.json: transformer_layer_cls_to_wrap = the decoder layer):
+        # one unit per decoder layer — 97 % of a 34 B model's parameters; frozen in this stage, so sharded for memory
+        # only.  Everything else (SVA layers, projectors, vision_query, image_newline, embeddings, final norm, lm_head)
+        # is the root unit of the reference; here it stays replicated and its gradients go through GradSync (the SVA
+        # modules are entered through forward_fused(), which module hooks do not see).
         from cambrian_amd.train.zero3 import zero3_finalize, zero3_parameters, zero3_wrap
         m = model.model
-        mods = list(m.layers) + list(m.vision_sampler_layers) + [m.vision_sampler_0, m.mm_projector] + \
-            [getattr(m, f"mm_projector_aux_{i}") for i in range(len(cfg.mm_vision_tower_aux_list))]
+        mods = list(m.layers)
         in_units = {id(p) for mod in mods for p in mod.parameters()}
         z3_units = zero3_wrap(mods)
         rest = [p for p in params if id(p) not in in_units]

@@ -212,13 +212,18 @@ class LlamaAttention(nn.Module):
                 o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                                    enable_gqa=self.nkv != self.nh)
             return _lin(self.o_proj, o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
-        if isinstance(attn_mask, KeyPadding):
-            attn_mask = attn_mask.dense()
         q = ops.rope(self.q_proj(x).view(B * S, self.nh, self.hd), cos, sin).view(B, S, self.nh, self.hd).transpose(1, 2)
         k = ops.rope(self.k_proj(x).view(B * S, self.nkv, self.hd), cos, sin).view(B, S, self.nkv, self.hd).transpose(1, 2)
         v = self.v_proj(x).view(B, S, self.nkv, self.hd).transpose(1, 2)
         if kv_out is not None:
             kv_out.append((k, v))
+        key_valid = attn_mask.key_valid if isinstance(attn_mask, KeyPadding) else None
+        if x.is_cuda and (attn_mask is None or key_valid is not None) and torch.is_grad_enabled() and q.requires_grad \
+                and ops.causal_attention_supported(q, k):     # trainable projections (finetune stage): same HIP attention
+            o = ops.causal_attention(q, k, v, key_valid)
+            return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))
+        if key_valid is not None:
+            attn_mask = attn_mask.dense()
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, is_causal=attn_mask is None,
                                            enable_gqa=self.nkv != self.nh)
         return self.o_proj(o.transpose(1, 2).reshape(B, S, self.nh * self.hd))

@@ -137,6 +137,18 @@ class BaseVisionTower(nn.Module):
             canon["pos"] = pos_fn(canon["pos"])
         return ViTTrunk(cfg, dtype).load_canonical(canon, self._target_device())
 
+    def _random_init_or_raise(self, why: str) -> None:
+        """No local checkpoint was found.  The reference fails here (``from_pretrained`` / the open_clip hub download
+        raise); silently running on random weights would hand ``load_pretrained_model()`` a model whose vision features are
+        noise, so random initialisation of the same architecture needs an explicit opt-in: ``CAMBRIAN_AMD_RANDOM_INIT=1``
+        (set by bench.py and the tests, which have no network for the released weights)."""
+        import os
+        if os.environ.get("CAMBRIAN_AMD_RANDOM_INIT", "0") not in ("1", "true", "True"):
+            raise FileNotFoundError(
+                f"{self.vision_tower_name}: no local checkpoint ({why}); put the weights under $CAMBRIAN_WEIGHTS_DIR or the HF "
+                f"cache, or set CAMBRIAN_AMD_RANDOM_INIT=1 to run on seeded random weights of the same architecture")
+        logger.warning(f"{self.vision_tower_name}: random-init weights ({why}; CAMBRIAN_AMD_RANDOM_INIT=1)")
+
     def _resample(self, feats, target):
         """Token-grid resize of the wrappers; differentiable when the tower trains."""
         if self.unfreeze_mm_vision_tower:

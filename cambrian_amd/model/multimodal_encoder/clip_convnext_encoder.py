@@ -73,7 +73,7 @@ class CLIPConvNextTower(BaseVisionTower):
                 canon = hf_convnext_to_canonical(sd, cfg.depths)
             logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
         else:
-            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
+            self._random_init_or_raise("no network for open_clip hub download")
             canon = ConvNeXtTrunk.random_canonical(cfg, gen)
         if self.unfreeze_mm_vision_tower:      # fp32 master parameters + autograd operators
             from .convnext_train import TrainableConvNeXt

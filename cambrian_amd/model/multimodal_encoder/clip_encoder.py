@@ -75,7 +75,7 @@ class ClipVisionTower(BaseVisionTower):
             canon = hf_clip_to_canonical(sd, cfg.num_layers if self.unfreeze_mm_vision_tower else (cfg.run_layers or cfg.num_layers))
             logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
         else:
-            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
+            self._random_init_or_raise("no network for from_pretrained")
             canon = ViTTrunk.random_canonical(cfg, gen)
         from .weight_maps import canonical_to_hf_clip, hf_clip_to_canonical as _from_hf
         self.vision_tower = self._make_vit(cfg, canon, dtype, ref_keys=(   # keys of HF CLIPVisionModel (clip_encoder.py:47)

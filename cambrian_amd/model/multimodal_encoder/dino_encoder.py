@@ -95,7 +95,7 @@ class DinoVisionTower(BaseVisionTower):
             canon = hf_dinov2_to_canonical(load_checkpoint_state(ckpt), native.num_layers, native.act == "swiglu")
             logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
         else:
-            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for from_pretrained)")
+            self._random_init_or_raise("no network for from_pretrained")
             canon = ViTTrunk.random_canonical(native, gen)
         # 37x37 -> e.g. 27x27 at 378 px: once at load when frozen, inside every forward (differentiably) when training
         from .weight_maps import canonical_to_hf_dinov2, hf_dinov2_to_canonical as _from_hf

@@ -87,7 +87,7 @@ class SiglipVisionTower(ClipVisionTower):
                 canon = hf_siglip_to_canonical(sd, cfg.num_layers)
             logger.info(f"{self.vision_tower_name}: weights from {ckpt}")
         else:
-            logger.warning(f"{self.vision_tower_name}: random-init weights (no network for open_clip hub download)")
+            self._random_init_or_raise("no network for open_clip hub download")
             canon = ViTTrunk.random_canonical(cfg, gen)
         from .weight_maps import canonical_to_timm_vit, timm_vit_to_canonical as _from_timm
         self.vision_tower = self._make_vit(cfg, canon, dtype, ref_keys=(   # keys of the timm trunk (siglip_encoder.py:55)

@@ -12,6 +12,9 @@ parallelism with a bucketed, backward-overlapped all-reduce(mean) is the right t
     by autograd, i.e. it overlaps the rest of the backward pass; buckets are filled in reverse registration order,
     which is the order autograd produces them;
   * ``finish()`` waits, and leaves ``p.grad`` as views into the averaged buckets (no copy back).
+The hook copies each finished gradient into its bucket slot (1.2 GB read + 1.2 GB written per step for the 303 M fp32
+gradients of the pre-training stage: ~0.4 ms of a 1.1 s step).  Pre-pointing ``p.grad`` at the bucket instead would make
+autograd ACCUMULATE into it (zero the bucket + read-modify-write: three passes instead of two), so the copy stays.
 Correct by construction at any world size; exercised on CPU with gloo at world_size 2 (tests/test_dp.py).
 """
 from __future__ import annotations
@@ -41,9 +44,11 @@ class GradSync:
     """Bucketed all-reduce(mean) of the gradients of ``params`` overlapped with backward."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0,
-                 process_group: Optional[dist.ProcessGroup] = None):
+                 process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
+        """``always_reduce``: issue the collectives even at world size 1 (tests: the RCCL path on a one-GPU box)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.reduce = self.world > 1 or (always_reduce and dist.is_initialized())
         plist = [p for p in params if p.requires_grad]
         # reverse order ~ the order in which autograd finishes them
         plist = list(reversed(plist))
@@ -71,7 +76,7 @@ class GradSync:
         b.views[i].copy_(p.grad)
         p.grad = b.views[i]
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
+        if b.pending == 0 and self.reduce:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
@@ -87,7 +92,7 @@ class GradSync:
                         else:
                             b.views[i].copy_(p.grad)
                         p.grad = b.views[i]
-                if self.world > 1:
+                if self.reduce:
                     b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if b.work is not None:
                 b.work.wait()

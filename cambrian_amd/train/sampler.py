@@ -96,13 +96,19 @@ class LengthGroupedSampler(Sampler):
 def rank_batches(indices: Sequence[int], rank: int, world_size: int, batch_size: int, drop_last: bool = True) -> List[List[int]]:
     """The per-step batches of one data-parallel rank: chunk ``rank`` of every megabatch of the sampler's order (the
     chunks are the length-balanced ones ``split_to_even_chunks`` produced).  A ragged last megabatch is dropped
-    (``drop_last``) or dealt round-robin."""
+    (``drop_last``) or — as ``torch.utils.data.DistributedSampler`` does — padded by wrapping around to the start of the
+    order until it divides by ``world_size``, then cut into ``world_size`` equal contiguous chunks: every rank gets the
+    same number (>= 1) of samples, so no rank ever sits out a step of the gradient collectives."""
     mega = world_size * batch_size
     out = []
     for start in range(0, len(indices), mega):
         block = list(indices[start:start + mega])
         if len(block) == mega:
             out.append(block[rank * batch_size:(rank + 1) * batch_size])
-        elif not drop_last:
-            out.append(block[rank::world_size])
+        elif not drop_last and block:
+            per = -(-len(block) // world_size)
+            pad = per * world_size - len(block)
+            src = list(indices)
+            block = block + [src[i % len(src)] for i in range(pad)]
+            out.append(block[rank * per:(rank + 1) * per])
     return out

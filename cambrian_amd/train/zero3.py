@@ -61,14 +61,31 @@ class Zero3Unit:
         self._pending = 0
         self.release()
         module.register_forward_pre_hook(lambda m, a: self.gather())
-        module.register_forward_hook(lambda m, a, o: self.release())
-        module.register_full_backward_pre_hook(lambda m, g: self._pre_backward())
+        module.register_forward_hook(self._post_forward)
         if self.trainable:
             for p in self.params:
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(self._on_grad)
-        else:
-            module.register_full_backward_hook(lambda m, gi, go: self.release())
+
+    # A plain tensor hook on the unit's output marks the start of its backward.  (Module backward hooks would wrap the
+    # output in a custom-Function view, which the in-LLM SVA hook — an in-place scatter into the layer's output,
+    # cambrian_llama.py:181-207 — is not allowed to modify.)  A frozen unit has no gradient hook to release it: it is
+    # dropped when the next unit's backward starts, the last one by finalize().
+    _bw_prev: Optional["Zero3Unit"] = None
+
+    def _post_forward(self, module, args, out):
+        self.release()
+        t = out if torch.is_tensor(out) else next((o for o in out if torch.is_tensor(o)), None)
+        if t is not None and t.requires_grad:
+            t.register_hook(self._grad_of_output)
+
+    def _grad_of_output(self, grad):
+        prev = Zero3Unit._bw_prev
+        if prev is not None and prev is not self and not prev.trainable and prev.resident:
+            prev.release()
+        Zero3Unit._bw_prev = self
+        self._pre_backward()
+        return grad
 
     # ---- residency -----------------------------------------------------------------------------------------------
     def gather(self) -> None:
@@ -126,6 +143,8 @@ class Zero3Unit:
             self._reduce_grads()
         elif self._resident:
             self.release()
+        if Zero3Unit._bw_prev is self:
+            Zero3Unit._bw_prev = None
 
     def full_state(self) -> List[torch.Tensor]:
         """Every parameter, materialised (for checkpointing / tests)."""

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# no network for the released weights: towers run on seeded random weights of the same architecture (explicit opt-in,
+# base_encoder.py::_random_init_or_raise)
+os.environ.setdefault("CAMBRIAN_AMD_RANDOM_INIT", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -116,3 +116,18 @@ def test_refused_branches(tmp_path):
             load_pretrained_model(str(tmp_path), None, name, device="cpu", **kw)
     with pytest.raises(FileNotFoundError):
         load_hf_state(str(tmp_path))
+
+
+def test_missing_tower_weights_raise_without_the_opt_in(monkeypatch):
+    """a tower with no local checkpoint must fail like the reference's from_pretrained does, not fall back to
+    random weights silently; CAMBRIAN_AMD_RANDOM_INIT=1 is the explicit opt-in the tests / bench use."""
+    from types import SimpleNamespace
+    import pytest
+    from cambrian_amd.model.multimodal_encoder.builder import build_vision_tower
+    monkeypatch.setenv("CAMBRIAN_AMD_RANDOM_INIT", "0")
+    monkeypatch.delenv("CAMBRIAN_WEIGHTS_DIR", raising=False)
+    cfg = SimpleNamespace(mm_vision_tower="openai/clip-vit-large-patch14-336", mm_vision_select_layer=-2,
+                          mm_vision_select_feature="patch", unfreeze_mm_vision_tower=False)
+    tower = build_vision_tower(cfg, delay_load=True)
+    with pytest.raises(FileNotFoundError, match="CAMBRIAN_AMD_RANDOM_INIT"):
+        tower.load_model()

@@ -105,7 +105,8 @@ def test_flash_key_padding_mask_matches_fp32_autograd(dev, B, S, H, HKV):
                     <= 3e-2 * kr.grad.abs().max().item()), only_diag
 
 
-def test_decoder_uses_hip_attention_for_collator_masks(dev, monkeypatch):
+@pytest.mark.parametrize("request_frozen", [True, False])
+def test_decoder_uses_hip_attention_for_collator_masks(dev, monkeypatch, request_frozen):
     """a real collator batch (non-trivial attention_mask) must stay on flash_bwd.hip in training mode —
     F.scaled_dot_product_attention is never reached."""
     import torch.nn.functional as F
@@ -116,6 +117,9 @@ def test_decoder_uses_hip_attention_for_collator_masks(dev, monkeypatch):
     torch.manual_seed(0)
     model = CL.LlamaBackbone(cfg, dev, torch.bfloat16)
     B, S = 2, 1024
+    frozen = request_frozen
+    for p_ in model.parameters():      # frozen = the pre-training stage (fused q|k|v GEMM); trainable = the finetune stage
+        p_.requires_grad_(not frozen)
     x = torch.randn(B, S, 512, device=dev, dtype=torch.bfloat16, requires_grad=True)
     mask = _collator_key_mask(B, S, [(336, 224), (224, 336)]).to(dev)
 

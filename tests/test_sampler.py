@@ -35,7 +35,11 @@ def test_rank_batches_partition_every_megabatch():
         loads = [sum(lengths[i] for i in per_rank[r][step]) for r in range(4)]
         assert max(loads) - min(loads) <= max(lengths)          # greedy LPT balance
     assert S.rank_batches(list(range(10)), 1, 2, 4) == [[4, 5, 6, 7]]
+    # ragged tail kept: padded by wrap-around to a multiple of the world size, every rank gets an equal, non-empty share
+    assert S.rank_batches(list(range(10)), 0, 2, 4, drop_last=False) == [[0, 1, 2, 3], [8]]
     assert S.rank_batches(list(range(10)), 1, 2, 4, drop_last=False) == [[4, 5, 6, 7], [9]]
+    tails = [S.rank_batches(list(range(17)), r, 4, 4, drop_last=False)[-1] for r in range(4)]   # one sample left for four ranks
+    assert tails == [[16], [0], [1], [2]]
     with pytest.raises(ValueError):
         S.LengthGroupedSampler(2, 2)
     with pytest.raises(AssertionError):
