@@ -173,29 +173,51 @@ def reference_cpu_run():
         return None
 
 
-def pmc_note():
-    path = os.path.join(ROOT, "profiles", "pmc_gemm256.json")
+PMC_FILES = {2590: "r02_pmc_gemm_p5.json", 256: "pmc_gemm256.json"}   # cmb_gemm_last_kernel id -> profiles/ file
+
+
+def pmc_record(kernel_id):
+    """The rocprofv3 PMC summary of the dominant kernel (tools/pmc_traffic.sh + tools/pmc_summarise.py, committed under
+    profiles/), or None when there is none for this kernel or the kernel's sources changed since it was taken (the
+    summary carries their sha256: a constant from an older kernel would silently go stale)."""
+    name = PMC_FILES.get(kernel_id)
+    if not name:
+        return None
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
-        return {"shape_MNK": d["shape"], "algorithmic_bytes": d["algorithmic_bytes_per_launch"],
-                "what": "rocprofv3 --pmc passes on the launch shape with the largest share of the kernel's time "
-                        "(profiles/pmc_gemm256.json): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; FETCH counts L2->fabric "
-                        "reads incl. Infinity-Cache hits"}
     except Exception:
         return None
+    if d.get("sources_sha256"):
+        import hashlib
+        sha = hashlib.sha256()
+        try:
+            for s in d.get("sources", []):
+                with open(os.path.join(ROOT, s), "rb") as f:
+                    sha.update(f.read())
+        except OSError:
+            return None
+        if sha.hexdigest() != d["sources_sha256"]:
+            return None
+    d["_file"] = name
+    return d
 
 
-def pmc_traffic():
+def pmc_note(kernel_id):
+    d = pmc_record(kernel_id)
+    if d is None:
+        return None
+    return {"shape_MNK": d["shape"], "algorithmic_bytes": d["algorithmic_bytes_per_launch"],
+            "what": f"rocprofv3 --pmc passes on the launch shape with the largest share of the kernel's time "
+                    f"(profiles/{d['_file']}): (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; FETCH counts L2->fabric "
+                    f"reads incl. Infinity-Cache hits"}
+
+
+def pmc_traffic(kernel_id):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-    MI355X_MICROARCH.md §HBM), collected by tools/pmc_traffic.sh over this same command and committed under profiles/;
-    null when no PMC summary for the current round is present."""
-    path = os.path.join(ROOT, "profiles", "pmc_gemm256.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    MI355X_MICROARCH.md §HBM); null when no valid PMC summary is present (pmc_record)."""
+    d = pmc_record(kernel_id)
+    return None if d is None else d.get("hbm_bytes_per_launch")
 
 
 def main():
@@ -367,17 +389,29 @@ def main():
                 ms = sum(x[0].elapsed_time(x[1]) for x in prof if sel(x))
                 n = sum(1 for x in prof if sel(x))
                 return fl, ms, n
-            f256, ms256, n256 = agg(lambda x: x[3] == torch.bfloat16 and x[5] == 256)
+            # the 256 x 256 tile is served by two kernels (cmb_gemm_last_kernel): the roofline object is about the one
+            # with the larger share of the step; the other is reported beside it
+            KNAMES = {2590: "cmb_gemm_detail::gemm_nt_p5_kernel (bf16, 256x256x64, 4 waves, fragments of the K tile in registers)",
+                      256: "cmb_gemm_detail::gemm_nt_256_kernel (bf16, 256x256x64, 8 waves)",
+                      2570: "cmb_gemm_detail::gemm_nt_p4_kernel", 2580: "cmb_gemm_detail::gemm_nt_p2_kernel"}
+            per = {kid: agg(lambda x, kid=kid: x[3] == torch.bfloat16 and x[5] == 256 and x[7] == kid) for kid in KNAMES}
+            dom = max(per, key=lambda kid: per[kid][1])
+            f256, ms256, n256 = per[dom]
             fall, msall, nall = agg(lambda x: x[3] == torch.bfloat16)
             ach = f256 / (ms256 * 1e-3) / 1e12 if ms256 > 0 else 0.0
-            line["roofline"] = {"bound": "mfma", "kernel": "cmb_gemm_detail::gemm_nt_256_kernel (bf16, 256x256x64, 8 waves)",
+            line["roofline"] = {"bound": "mfma", "kernel": KNAMES[dom],
                                 "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(), "traffic_of": pmc_note(),
+                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(dom), "traffic_of": pmc_note(dom),
                                 "launches": n256, "avg_launch_us": ms256 * 1e3 / max(n256, 1),
                                 "flop_per_launch_avg": f256 / max(n256, 1),
                                 "share_of_step": ms256 / (elapsed * 1e3),
                                 "flop_model": "2*M*N*K per launch, summed over the launches of the timed region",
                                 "peak_source": "MI355X_MICROARCH.md: 2.5 PFLOP/s dense bf16 MFMA"}
+            others = {KNAMES[k].split(" ")[0]: {"achieved": v[0] / (v[1] * 1e-3) / 1e12, "launches": v[2],
+                                                "avg_launch_us": v[1] * 1e3 / v[2], "share_of_step": v[1] / (elapsed * 1e3)}
+                      for k, v in per.items() if k != dom and v[2]}
+            if others:
+                line["roofline"]["other_256_tile_kernels"] = others
             if args.gemm_report:
                 line["roofline"]["all_bf16_gemm"] = {"achieved": fall / (msall * 1e-3) / 1e12 if msall > 0 else 0.0,
                                                      "launches": nall, "share_of_step": msall / (elapsed * 1e3)}

@@ -242,7 +242,7 @@ static int tile_override() {
 }
 static bool use_tile256(int M, int N, int splits, int hint) {
   const int ov = hint ? hint : tile_override();
-  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2580 || (ov >= 2600 && ov < 3000)) return true;
+  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2580 || ov == 2590 || (ov >= 2600 && ov < 3000)) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -267,6 +267,8 @@ static bool p4_ok(const GemmParams& p, int splits, int ns) {
   const int last = p.K - (splits - 1) * p.k_per_split;
   return last / 32 >= ns && p.k_per_split / 32 >= ns;
 }
+
+static thread_local int g_last_kernel = 0;  // cmb_gemm_last_kernel()
 
 template <typename T>
 int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
@@ -311,22 +313,29 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   }
   int rc;
   if constexpr (sizeof(T) == 2) {
-    // tile_hint / CMB_GEMM_TILE: 0 = cost model (128x128 or the 8-wave 256x256 kernel) | 128 | 256 / 2560 / 2561 (8-wave
-    // kernel, schedule 0 / 0 / 1) | 2570 (persistent 4-wave kernel, gemm_p4.hip) | 2580 (persistent 256x128, two workgroups
-    // per CU) | 2600 + bits (ablations of the 4-wave kernel, lab builds).  The persistent kernels are opt-in: on the
-    // path's shapes they measure within +-7 % of the 8-wave kernel (profiles/r02_gemm_lab.md), so the latter stays default.
+    // tile_hint / CMB_GEMM_TILE: 0 = cost model (128x128 tile, or a 256x256 tile: the 4-wave register-buffered kernel
+    // gemm_nt_p5_kernel where it applies, else the 8-wave kernel) | 128 | 256 (as the cost model's 256 branch) | 2560 /
+    // 2561 (8-wave kernel, schedule 0 / 1) | 2570 (4-wave ring kernel, gemm_nt_p4_kernel) | 2580 (256x128, two workgroups
+    // per CU) | 2590 (gemm_nt_p5_kernel) | 2600 + bits / 2700 + bits (ablations of the ring / p5 kernels, lab builds).
+    // Measured on the path's shapes (profiles/r02_gemm_lab.md): p5 is 3-11 % ahead of the 8-wave kernel when N is a
+    // multiple of 256 and up to 40 % behind when it is not (N = 384, 1152: the ragged tile column leaves through the
+    // generic epilogue and drains the DMA pipeline), so the default takes it for N % 256 == 0 only; the ring and the
+    // 256x128 kernels are behind everywhere.
     const int ov = d->tile_hint ? d->tile_hint : tile_override();
-    const bool want_p4 = ov == 2570 || (ov >= 2600 && ov < 3000);
+    const bool want_p4 = ov == 2570 || (ov >= 2600 && ov < 2700);
     if (!use_tile256(p.M, p.N, splits, d->tile_hint) || !tile_span_fits_u32(p.a_map, p.ldb))
-      rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+      g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
     else if (ov == 2580 && p4_ok(p, splits, 3))
-      rc = launch_gemm_p2_bf16(p, splits, s);
+      g_last_kernel = 2580, rc = launch_gemm_p2_bf16(p, splits, s);
+    else if ((ov == 2590 || (ov >= 2700 && ov < 2800) || ((ov == 0 || ov == 256) && p.N % 256 == 0)) &&
+             p4_ok(p, splits, 4))  // two 64-deep tiles per item
+      g_last_kernel = 2590, rc = launch_gemm_p5_bf16(p, splits, ov >= 2700 ? ov - 2700 : 0, s);
     else if (want_p4 && p4_ok(p, splits, 5))
-      rc = launch_gemm_p4_bf16(p, splits, 5, ov >= 2600 ? ov - 2600 : 0, s);
+      g_last_kernel = 2570, rc = launch_gemm_p4_bf16(p, splits, 5, ov >= 2600 ? ov - 2600 : 0, s);
     else
-      rc = launch_gemm256_bf16(p, splits, ov == 2561 ? 1 : 0, s);
+      g_last_kernel = 256, rc = launch_gemm256_bf16(p, splits, ov == 2561 ? 1 : 0, s);
   } else {
-    rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+    g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   }
   if (rc != CMB_OK) return rc;
   if (p.slabs) {
@@ -350,6 +359,8 @@ extern "C" int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, i
   if (dtype != CMB_BF16) return 128;
   return use_tile256((int)M, (int)N, split_k > 1 ? split_k : 1, tile_hint) ? 256 : 128;
 }
+
+extern "C" int cmb_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return CMB_ERR_BAD_ARG;

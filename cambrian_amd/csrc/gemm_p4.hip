@@ -381,144 +381,7 @@ __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, con
 
     run_stages(cit.nk, relax);
 
-    // ---- tile finished: epilogue straight from the accumulators ---------------------------------------------------
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // last MFMA -> accumulator reads inside asm statements below
-    int e_lane = lane;
-    asm volatile("" : "+v"(e_lane));  // opaque: nothing below is hoisted above the stage loop (register pressure)
-    const int half = e_lane >> 5;
-    const int gn0 = cit.n0 + wn * 128 + 8 * half;  // + 32 j + 16 pr
-    // One (i, j, pr) group = 8 consecutive columns of one output row per lane.  The accumulator elements are read with
-    // v_accvgpr_read at the point of use (asm, "a" operands): left to itself the register allocator copies all 256 of
-    // them into VGPRs at the loop exit and spills loop-carried address registers to make room.
-    auto take8 = [&](auto i_c, auto j_c, auto pr_c, float (&v)[8]) {
-      constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, pr = decltype(pr_c)::value;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // vdst = column group 2 pr (n = 16 pr + 4 half + e), src = group 2 pr + 1 (n = 16 pr + 8 + 4 half + e)
-        uint32_t lo, hi;
-        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\ts_nop 1"
-                     : "=&v"(lo), "=&v"(hi)
-                     : "a"(acc[i][j][8 * pr + e]), "a"(acc[i][j][8 * pr + 4 + e]));
-        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-        v[e] = __uint_as_float(r[0]);
-        v[4 + e] = __uint_as_float(r[1]);
-      }
-    };
-    const bool rows_all = cit.m0 + wm * 128 + 128 <= p.M;  // every row of the wave's 128 is in range
-    const bool fast = !p.slabs && !p.out_f32 && !p.a_scale && !p.b_scale && !p.P && cit.n0 + 256 <= p.N &&
-                      (!p.R || rows_all);  // the residual path counts its stores (see half_tile)
-    relax = fast && rows_all;  // exactly 32 stores were issued behind the DMA pieces the next two stages wait for
-    if (fast) {
-      // bf16 C with optional bias / activation / LayerScale / residual.  Column vectors come through the scalar cache
-      // (no vmcnt wait); the residual is loaded for half of the wave's columns at a time, all loads of a half ahead of
-      // that half's stores (a vector load issued after a store can only be waited for together with the store).
-      const float* bias_w = p.bias ? p.bias + cit.n0 + wn * 128 : nullptr;
-      const float* cs_w = p.colscale ? p.colscale + cit.n0 + wn * 128 : nullptr;
-      const bool upper = half != 0;
-      int64_t crow[4];
-      bool okr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
-        okr[i] = gm < p.M;
-        crow[i] = row_off(p.c_map, (uint32_t)(okr[i] ? gm : p.M - 1)) + gn0;
-      }
-      // The residual loads are issued and waited for by hand (asm, counted vmcnt).  Left to hipcc, their pending-load
-      // state leaks out of the epilogue — its scoreboard cannot tell that they are all consumed — and it parks an
-      // s_waitcnt vmcnt(0) inside the next tile's stage loop, in front of the ds_reads that reuse those registers:
-      // the LDS-DMA pipeline then drains every stage.  The stores stay ordinary stores; a store is only issued when
-      // some lane's row is in range, which is why the counted waits below assume the row block is in range for the
-      // wave (otherwise the wave-uniform `rows_ok` falls back to a full drain).
-      auto half_tile = [&](auto h_c, auto r_c) {  // column groups g8 = 4 h .. 4 h + 3 (j = 2 h, 2 h + 1)
-        constexpr int h = decltype(h_c)::value;
-        constexpr bool HAS_R = decltype(r_c)::value;
-        bf16x8_t res[4][4];
-        if constexpr (HAS_R) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
-            const bf16_t* rrow =
-                reinterpret_cast<const bf16_t*>(p.R) + row_off(p.r_map, (uint32_t)(gm < p.M ? gm : p.M - 1)) + gn0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)  // asm: hipcc must not see these loads (comment at the top of half_tile)
-              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(res[i][g]) : "v"(rrow + 16 * (4 * h + g)) : "memory");
-          }
-        }
-        auto group = [&](auto g_c) {
-          constexpr int g = decltype(g_c)::value, g8 = 4 * h + g, j = g8 >> 1, pr = g8 & 1;
-          float bias[8], cs[8];
-          if (bias_w) p4_colvec(bias_w + 16 * g8, upper, bias);
-          if (cs_w) p4_colvec(cs_w + 16 * g8, upper, cs);
-          auto row = [&](auto i_c) {
-            constexpr int i = decltype(i_c)::value;
-            float v[8];
-            take8(i_c, std::integral_constant<int, j>{}, std::integral_constant<int, pr>{}, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-            if (bias_w) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += bias[e];
-            }
-            if constexpr (ACT == CMB_ACT_GELU_ERF) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = cmb_gelu_erf_fast(v[e]);
-            } else if constexpr (ACT != CMB_ACT_NONE) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
-            }
-            if (cs_w) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= cs[e];
-            }
-            if constexpr (HAS_R) {
-              // load number 4 i + g of this half; behind it: 15 - (4 i + g) loads and the 4 g + i stores issued so far
-              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(res[i][g]) : "n"(15 - 3 * i + 3 * g));
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)res[i][g][e];
-            }
-            if (okr[i])
-              *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16_t*>(p.C) + crow[i] + 16 * g8) =
-                  cvt8_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            P4_FENCE();
-          };
-          row(I0{}); row(I1{}); row(I2{}); row(I3{});
-        };
-        group(I0{}); group(I1{}); group(I2{}); group(I3{});
-      };
-#ifndef P4_X2
-      if (p.R) {
-        half_tile(I0{}, std::true_type{});
-        half_tile(I1{}, std::true_type{});
-      } else
-#endif
-      {
-        half_tile(I0{}, std::false_type{});
-        half_tile(I1{}, std::false_type{});
-      }
-    } else {
-      // every other epilogue form (split-K slabs, fp32 C with beta, pre-activation copy, ragged N): group by group
-      // through the shared helper
-      auto slow = [&](auto i_c, auto j_c, auto pr_c) {
-        constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value, pr = decltype(pr_c)::value;
-        float v[8];
-        take8(i_c, j_c, pr_c, v);
-        const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
-        const int gn = gn0 + 32 * j + 16 * pr;
-        if (gm < p.M && gn < p.N) gemm_epilogue8<bf16_t, ACT>(p, cit.kz, gm, gn, v);  // slabs are launched with ACT none
-        P4_FENCE();
-      };
-      auto slow_row = [&](auto i_c) {
-        slow(i_c, I0{}, I0{}); slow(i_c, I0{}, I1{}); slow(i_c, I1{}, I0{}); slow(i_c, I1{}, I1{});
-        slow(i_c, I2{}, I0{}); slow(i_c, I2{}, I1{}); slow(i_c, I3{}, I0{}); slow(i_c, I3{}, I1{});
-      };
-#ifndef P4_X1
-      slow_row(I0{}); slow_row(I1{}); slow_row(I2{}); slow_row(I3{});
-#endif
-      // The helper's loads sit in run-time branches whose uses the compiler cannot pair up: it would carry "a load may
-      // still be pending" into the next tile and park an s_waitcnt vmcnt(0) inside the stage loop (draining the
-      // LDS-DMA every stage).  Retire them here, where it only costs this rare path a store drain.
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    }
+#include "gemm_p4_epilogue.inc"
     // the cursor is now inside item c_item + stride (nk >= NS is a launch condition): describe the one after it
     const int n2 = c_item + 2 * stride;
     nxt = src_of(n2 <= last_item ? n2 : last_item);
@@ -864,6 +727,272 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_p2_kernel(const GemmParams p, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// =====================================================================================================================
+// gemm_nt_p5_kernel — the 4-wave persistent kernel with 64-deep K tiles, the WHOLE tile's fragments held in registers
+// and a two-buffer LDS (2 x 64 KiB).  Differences from gemm_nt_p4_kernel and why (profiles/r02_gemm_lab.md):
+//   * a stage row is 128 B = one full cache line per tile row (the 32-deep stages of the ring fetch every line of A
+//     and B as two half-lines, one stage apart: twice the requests to the vector cache / L2 for the same bytes);
+//   * the fragments of all four 16-deep sub-steps live in 128 VGPRs, so a buffer is free for the DMA of tile t + 2 as
+//     soon as every wave has READ tile t (barrier B1, a quarter into the tile) — LDS + registers together hold three
+//     tiles, and the DMA of a tile has a whole tile (2048 MFMA cycles) before it is needed;
+//   * two barriers and ONE counted vmcnt wait per 64 MFMAs (the ring: one of each per 32).
+// This is the loop structure of the vendor's 256 x 256 x 64 direct-to-LDS kernel, which runs the same problem sizes
+// 1.2-1.4x faster than the ring; it is written here from scratch around this file's cursor / epilogue machinery.
+//
+// Tile t of an item, buffer c = t & 1 (holds tile t), buffer o = the other (tile t + 1 landing); MFMA slot L = 0..63,
+// sub-step ks = L >> 4 uses fragment set ks:
+//     L  0..15   one ds_read_b128 per slot: sets 2, 3 <- buffer c
+//     after 17   s_waitcnt lgkmcnt(0); s_barrier (B1)   every wave holds all of tile t: buffer c is free
+//     L 18..48   even slots: LDS-DMA piece (L - 18) / 2 of tile t + 2 -> buffer c  (16 pieces per wave: 8 A, 8 B)
+//     after 49   s_waitcnt vmcnt(16); s_barrier (B2)    tile t + 1 (the 16 pieces before this tile's) has landed
+//     L 50..63   sets 0, 1 <- buffer o (16 reads in 14 slots), cursor + 128 B, buffers swap
+// Across items: the last two tiles of an item stage the first two tiles of the workgroup's next item (the cursor is
+// re-described two tiles before the end; K >= 128 per item is a launch condition), so the epilogue runs with the
+// next item's tile 0 already in registers and tile 1 in flight.  The first B2 after an epilogue that issued exactly
+// 32 stores waits with vmcnt(16 + 32): the stores are younger than the pieces it needs.
+//
+// LDS buffer: A 256 rows x 128 B then B 256 rows x 128 B, chunk c of row r at r * 128 + ((c ^ gl_swz(r)) << 4)
+// (gemm_layout.h); a DMA piece is 8 rows (8 lanes x 16 B per row), wave w stages rows [64 w, 64 w + 64) of both.
+constexpr int kP5Op = 256 * 128;   // bytes of one operand's tile
+constexpr int kP5Buf = 2 * kP5Op;  // A then B
+
+struct P5Src {
+  uint32_t a_off[8], b_off[8];  // per-lane byte offsets of the wave's 8 + 8 pieces
+  const char* a_base;           // wave-uniform: the cursor's tile
+  const char* b_base;
+};
+
+// VAR (lab builds, timing only — 1, 4, 8 compute garbage): 1 = no in-loop DMA, 2 = s_nop 4 in front of every piece,
+// 4 = frozen cursor (every piece re-reads the item's first tile: cache-hot), 8 = unswizzled DMA source, 16 = B1 three
+// slots later with a piece every 2 slots, 32 = a piece every 2 slots, 64 = buffer_load ... lds form of the piece.
+template <int ACT, int VAR>
+__global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, const int n_items) {
+  constexpr bool kNoDma = VAR & 1, kNoNop = !(VAR & 2), kFrozen = VAR & 4, kLinear = VAR & 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16x8_t frag_t;
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 3> I3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int stride = (int)gridDim.x;
+  const int first_item = (int)blockIdx.x;
+  const int last_item = first_item + ((n_items - 1 - first_item) / stride) * stride;
+
+  // ---- DMA side -------------------------------------------------------------------------------------------------
+  const int d_row = wave * 64 + (lane >> 3);  // + 8 i
+  const uint32_t dma_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem)) + (uint32_t)wave * 8192u;
+  auto src_of = [&](int item) -> P5Src {
+    P5Src r;
+    const P4Item it = p4_item(p, item, ntiles);
+    const int64_t a_row0 = row_off(p.a_map, (uint32_t)it.m0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = d_row + 8 * i;
+      const int chunk = kLinear ? (lane & 7) : ((lane & 7) ^ gl_swz(row));
+      int gm = it.m0 + row;
+      gm = gm < p.M ? gm : p.M - 1;
+      r.a_off[i] = (uint32_t)((row_off(p.a_map, (uint32_t)gm) - a_row0) * 2 + chunk * 16);
+      int gn = it.n0 + row;
+      gn = gn < p.N ? gn : p.N - 1;
+      r.b_off[i] = (uint32_t)((int64_t)(gn - it.n0) * p.ldb * 2 + chunk * 16);
+    }
+    r.a_base = p4_uniform_ptr(p.A + (a_row0 + it.kbeg) * 2);
+    r.b_base = p4_uniform_ptr(p.B + ((int64_t)it.n0 * p.ldb + it.kbeg) * 2);
+    return r;
+  };
+  P5Src cur = src_of(first_item);
+  // piece pc (0..7 = A rows, 8..15 = B rows of this wave) of the cursor's tile -> buffer at LDS byte `buf` (+ this
+  // wave's row block).  One statement: M0, the wait states an SGPR base re-read from a spill needs (gemm_nt_p4_kernel),
+  // the DMA.
+  auto piece = [&](uint32_t buf, auto pc_c) {
+    constexpr int pc = decltype(pc_c)::value;
+    P5Src& c = cur;
+    if constexpr ((VAR & 64) != 0) {  // the buffer form of the same piece (timing probe)
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      const uint64_t b = (uint64_t)(pc < 8 ? c.a_base : c.b_base);
+      const u32x4_t srd = {(uint32_t)b, (uint32_t)(b >> 32) & 0xffffu, 0xffffffffu, 0x00020000u};
+      const uint32_t vo = pc < 8 ? c.a_off[pc] : c.b_off[pc - 8];
+      asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                   :
+                   : "v"(vo), "s"(srd), "s"(buf), "n"(pc < 8 ? pc * 1024 : kP5Op + (pc - 8) * 1024)
+                   : "memory", "m0", "scc");
+    } else if constexpr (kNoNop) {
+      if constexpr (pc < 8)
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(c.a_off[pc]), "s"(c.a_base), "s"(buf), "n"(pc * 1024)
+                     : "memory", "m0", "scc");
+      else
+        asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(c.b_off[pc - 8]), "s"(c.b_base), "s"(buf), "n"(kP5Op + (pc - 8) * 1024)
+                     : "memory", "m0", "scc");
+    } else if constexpr (pc < 8)
+      asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :
+                   : "v"(c.a_off[pc]), "s"(c.a_base), "s"(buf), "n"(pc * 1024)
+                   : "memory", "m0", "scc");
+    else
+      asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :
+                   : "v"(c.b_off[pc - 8]), "s"(c.b_base), "s"(buf), "n"(kP5Op + (pc - 8) * 1024)
+                   : "memory", "m0", "scc");
+  };
+  auto advance = [&]() {
+    if constexpr (kFrozen) return;
+    cur.a_base += 128;
+    cur.b_base += 128;
+  };
+
+  // ---- fragment read addresses (bytes inside a buffer): row (lane & 31) of block i, logical chunk 2 ks + (lane >> 5)
+  uint32_t a_rd[4], b_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int koff = ((2 * ks + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4;  // gl_swz(row) = (lane >> 1) & 7 for every block
+    a_rd[ks] = (uint32_t)((wm * 128 + (lane & 31)) * 128 + koff);
+    b_rd[ks] = (uint32_t)(kP5Op + (wn * 128 + (lane & 31)) * 128 + koff);
+  }
+  f32x16_t acc[4][4];
+  frag_t fa[4][4], fb[4][4];  // [ks][block]
+  auto read_frag = [&](int ks, uint32_t buf_off, int which) {  // which: 0..3 = A row block, 4..7 = B column block
+    const char* base = smem + buf_off;
+    if (which < 4) fa[ks][which] = *reinterpret_cast<const frag_t*>(base + a_rd[ks] + which * 4096);
+    else fb[ks][which - 4] = *reinterpret_cast<const frag_t*>(base + b_rd[ks] + (which - 4) * 4096);
+  };
+  uint32_t off_c = 0, off_o = kP5Buf;  // LDS byte offsets of buffer c / o
+
+  // ---- prologue: tiles 0 and 1 of the first item; tile 0's first half into sets 0, 1 -----------------------------------
+  auto issue_tile = [&](uint32_t buf) {
+    piece(buf, std::integral_constant<int, 0>{}); piece(buf, std::integral_constant<int, 1>{});
+    piece(buf, std::integral_constant<int, 2>{}); piece(buf, std::integral_constant<int, 3>{});
+    piece(buf, std::integral_constant<int, 4>{}); piece(buf, std::integral_constant<int, 5>{});
+    piece(buf, std::integral_constant<int, 6>{}); piece(buf, std::integral_constant<int, 7>{});
+    piece(buf, std::integral_constant<int, 8>{}); piece(buf, std::integral_constant<int, 9>{});
+    piece(buf, std::integral_constant<int, 10>{}); piece(buf, std::integral_constant<int, 11>{});
+    piece(buf, std::integral_constant<int, 12>{}); piece(buf, std::integral_constant<int, 13>{});
+    piece(buf, std::integral_constant<int, 14>{}); piece(buf, std::integral_constant<int, 15>{});
+  };
+  issue_tile(dma_lds);
+  advance();
+  issue_tile(dma_lds + kP5Buf);
+  advance();
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  P4_BARRIER();
+#pragma unroll
+  for (int w = 0; w < 8; ++w) read_frag(0, 0u, p4_read_order(w));
+#pragma unroll
+  for (int w = 0; w < 8; ++w) read_frag(1, 0u, p4_read_order(w));
+
+  // ---- one tile ------------------------------------------------------------------------------------------------------
+  // kB1 / kB2: the MFMA slots the two barriers follow; PH: this wave issues its pieces on odd (1) or even (0) slots
+  constexpr int kStep = (VAR & 48) ? 2 : 3;  // MFMA slots between two DMA pieces
+  constexpr int kB1 = (VAR & 16) ? 20 : 17, kB2 = kB1 + 33, kTail = 63 - kB2, kDouble = 16 - kTail;
+  auto tile = [&](auto relax_c, auto ph_c) __attribute__((always_inline)) {
+    constexpr bool RELAX = decltype(relax_c)::value;
+    constexpr int PH = decltype(ph_c)::value, P0 = kB1 + 1 + PH;
+    auto extras = [&](auto l_c) {
+      constexpr int L = decltype(l_c)::value;
+      if constexpr (L < 16) read_frag(2 + (L >> 3), off_c, p4_read_order(L & 7));
+      if constexpr (L == kB1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P4_BARRIER();
+      }
+      if constexpr (L >= P0 && L <= P0 + 15 * kStep && ((L - P0) % kStep) == 0 && !kNoDma)
+        piece(dma_lds + off_c, std::integral_constant<int, (L - P0) / kStep>{});
+      if constexpr (L == kB2) {  // the pieces of this tile issued so far may stay in flight
+        constexpr int mine = (kB2 - P0) / kStep + 1 > 16 ? 16 : (kB2 - P0) / kStep + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(mine + (RELAX ? 32 : 0)) : "memory");
+        P4_BARRIER();
+      }
+      if constexpr (L == 63) advance();
+      if constexpr (L > kB2) {  // sets 0, 1 <- buffer o: 16 reads in kTail slots, the first kDouble slots carry two
+        constexpr int sl = L - kB2 - 1, r0 = sl < kDouble ? 2 * sl : sl + kDouble;
+        read_frag(r0 >> 3, off_o, p4_read_order(r0 & 7));
+        if constexpr (sl < kDouble) read_frag((r0 + 1) >> 3, off_o, p4_read_order((r0 + 1) & 7));
+      }
+      if constexpr (L == 63) {
+        const uint32_t t = off_c;
+        off_c = off_o;
+        off_o = t;
+      }
+    };
+    auto mfma_at = [&](auto l_c) {
+      constexpr int L = decltype(l_c)::value, t = L & 15, i = t >> 2, j = t & 3, ks = L >> 4;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+      extras(l_c);
+      P4_FENCE();
+    };
+#define P5_M(n) mfma_at(std::integral_constant<int, n>{})
+#define P5_M8(n) P5_M(n); P5_M(n + 1); P5_M(n + 2); P5_M(n + 3); P5_M(n + 4); P5_M(n + 5); P5_M(n + 6); P5_M(n + 7)
+    P5_M8(0); P5_M8(8); P5_M8(16); P5_M8(24); P5_M8(32); P5_M8(40); P5_M8(48); P5_M8(56);
+#undef P5_M8
+#undef P5_M
+  };
+  auto run_tile = [&](bool rl) __attribute__((always_inline)) {
+    if (rl) tile(std::true_type{}, std::integral_constant<int, 0>{});
+    else tile(std::false_type{}, std::integral_constant<int, 0>{});
+  };
+
+  bool relax = false;
+#pragma unroll 1
+  for (int c_item = first_item; c_item < n_items; c_item += stride) {
+    const P4Item cit = p4_item(p, c_item, ntiles);
+    const int nt = cit.nk >> 1;  // 64-deep tiles of this item (>= 2)
+    const int n1 = c_item + stride;
+    const int next_item = n1 <= last_item ? n1 : last_item;  // past the last item the cursor re-reads it (never consumed)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // tile k stages tile k + 2: of this item while k + 2 < nt, else tile k + 2 - nt of the next item
+    if (nt == 2) cur = src_of(next_item);
+    run_tile(relax);
+#pragma unroll 1
+    for (int k = 1; k < nt; ++k) {
+      if (k == nt - 2) cur = src_of(next_item);
+      run_tile(false);
+    }
+
+#include "gemm_p4_epilogue.inc"
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+template <int ACT, int VAR>
+int launch_p5_act(GemmParams& p, int splits, hipStream_t s) {
+  constexpr int smem = 2 * kP5Buf;
+  static bool attr_done = false;
+  static int n_cu = 0;
+  auto kern = gemm_nt_p5_kernel<ACT, VAR>;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+        hipSuccess)
+      return CMB_ERR_LAUNCH;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+      return CMB_ERR_LAUNCH;
+    n_cu -= n_cu % 8;  // whole XCD rounds: item % 8 == block % 8 in every round
+    if (n_cu <= 0) return CMB_ERR_LAUNCH;
+    attr_done = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  const int n_items = p.tiles_m * p.tiles_n * splits;
+  const int grid = n_items < n_cu ? n_items : n_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, p, n_items);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
 template <int ACT>
 int launch_p2_act(GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem = kP2NS * kP2Stage;
@@ -938,6 +1067,35 @@ int launch_gemm_p2_bf16(GemmParams& p, int splits, hipStream_t s) {
     case CMB_ACT_QUICK_GELU: return launch_p2_act<CMB_ACT_QUICK_GELU>(p, splits, s);
     case CMB_ACT_SILU: return launch_p2_act<CMB_ACT_SILU>(p, splits, s);
     default: return launch_p2_act<CMB_ACT_NONE>(p, splits, s);
+  }
+}
+
+int launch_gemm_p5_bf16(GemmParams& p, int splits, int var, hipStream_t s) {
+#ifdef CMB_GEMM_LAB
+  switch (var) {
+    case 1: return launch_p5_act<CMB_ACT_NONE, 1>(p, splits, s);
+    case 2: return launch_p5_act<CMB_ACT_NONE, 2>(p, splits, s);
+    case 4: return launch_p5_act<CMB_ACT_NONE, 4>(p, splits, s);
+    case 6: return launch_p5_act<CMB_ACT_NONE, 6>(p, splits, s);
+    case 8: return launch_p5_act<CMB_ACT_NONE, 8>(p, splits, s);
+    case 10: return launch_p5_act<CMB_ACT_NONE, 10>(p, splits, s);
+    case 12: return launch_p5_act<CMB_ACT_NONE, 12>(p, splits, s);
+    case 16: return launch_p5_act<CMB_ACT_NONE, 16>(p, splits, s);
+    case 17: return launch_p5_act<CMB_ACT_NONE, 17>(p, splits, s);
+    case 18: return launch_p5_act<CMB_ACT_NONE, 18>(p, splits, s);
+    case 32: return launch_p5_act<CMB_ACT_NONE, 32>(p, splits, s);
+    case 34: return launch_p5_act<CMB_ACT_NONE, 34>(p, splits, s);
+    case 80: return launch_p5_act<CMB_ACT_NONE, 80>(p, splits, s);
+    default: break;
+  }
+#endif
+  (void)var;
+  switch (p.slabs ? CMB_ACT_NONE : p.act) {
+    case CMB_ACT_GELU_ERF: return launch_p5_act<CMB_ACT_GELU_ERF, 0>(p, splits, s);
+    case CMB_ACT_GELU_TANH: return launch_p5_act<CMB_ACT_GELU_TANH, 0>(p, splits, s);
+    case CMB_ACT_QUICK_GELU: return launch_p5_act<CMB_ACT_QUICK_GELU, 0>(p, splits, s);
+    case CMB_ACT_SILU: return launch_p5_act<CMB_ACT_SILU, 0>(p, splits, s);
+    default: return launch_p5_act<CMB_ACT_NONE, 0>(p, splits, s);
   }
 }
 

@@ -88,6 +88,7 @@ SIGNATURES = {
     "cmb_abi_version": (C.c_int, []),
     "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
     "cmb_gemm_tile": (C.c_int, [C.c_int, _i64, _i64, _i32, _i32]),
+    "cmb_gemm_last_kernel": (C.c_int, []),
     "cmb_quantize_fp8_rows": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),

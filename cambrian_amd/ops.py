@@ -128,7 +128,8 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K, dt, split_k, tile_used, (M, N, K, act, out.dtype == torch.float32)))
+        prof.append((e0, e1, 2.0 * M * N * K, dt, split_k, tile_used, (M, N, K, act, out.dtype == torch.float32),
+                     L.load().cmb_gemm_last_kernel()))
     return out
 
 
@@ -234,7 +235,7 @@ def fp8_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
             and weight.shape[0] % 8 == 0 and weight.dtype in (torch.bfloat16, torch.float32))
 
 
-# bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k, tile) per GEMM launch
+# bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k, tile, shape, kernel id) per GEMM launch
 GEMM_PROFILE = None
 GEMM_PROFILE_TILE = 0  # 0 = time every GEMM launch; 128 / 256 = only launches of that tile configuration
 

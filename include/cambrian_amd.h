@@ -110,6 +110,10 @@ int cmb_quantize_fp8_rows(int dtype, const void* x, int64_t ldx, int64_t rows, i
 /* block tile (128 or 256) cmb_gemm would run for this problem — lets the caller label profiles / rooflines per
  * kernel configuration.  dtype CMB_F32 always answers 128. */
 int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint);
+/* which kernel the calling thread's most recent cmb_gemm launched (0 before the first): 128 = 128x128 tile kernel,
+ * 256 = 8-wave 256x256 kernel (gemm256.hip), 2590 = 4-wave register-buffered 256x256 kernel (gemm_nt_p5_kernel),
+ * 2570 / 2580 = the opt-in persistent ring / 256x128 kernels.  For labelling profiles and rooflines per kernel. */
+int cmb_gemm_last_kernel(void);
 
 /* out[C, R_pad] = in[R, C]^T, zero-filling columns R..R_pad-1 (R_pad >= R). Used to put the
  * reduction dimension innermost for weight-gradient GEMMs (autograd of the linears above). */

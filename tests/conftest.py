@@ -35,3 +35,17 @@ def rel_err(a, b):
 # stated tolerances: fp32 path = exact-fp32 MFMA / VALU kernels vs fp32 CPU oracle;
 # bf16 path = bf16 storage, fp32 accumulation, vs the same fp32 oracle.
 TOL = {"fp32": 2e-5, "bf16": 2e-2}
+
+
+def fit_err(a, b):
+    """(|slope - 1|, relative L2 error) of ``a`` against the reference ``b``: slope = <a, b> / <b, b>.  A max-abs bound of
+    a few percent would let a SYSTEMATIC scale error of that size through; the least-squares slope sees a 0.5 % scale
+    error even under bf16 rounding noise (which is zero-mean), and the L2 error averages the noise down."""
+    import torch
+    a = a.detach().double().flatten().cpu()
+    b = b.detach().double().flatten().cpu()
+    bb = float((b * b).sum())
+    if bb == 0.0:
+        return 0.0, float(a.norm())
+    slope = float((a * b).sum()) / bb
+    return abs(slope - 1.0), float((a - b).norm() / b.norm())
