@@ -48,6 +48,17 @@ __device__ __forceinline__ uint8_t kv_byte(const FlashParams& p, int b, int t, i
   return p.key_valid ? p.key_valid[(int64_t)b * p.S + t * 64 + lane] : (uint8_t)1;
 }
 
+// Which of this lane's 16 keys of one 32-key half tile are open to its query: bit (r & 3) + 8 (r >> 2) <-> accumulator
+// element r (key = half tile base + 4 g + that bit index).  `vw` is the tile's 64-bit key-validity ballot; `dq` = the
+// lane's query index minus the half tile's first key: the query's own key stays open even when it is padding (the
+// diagonal of the collator mask, train_fsdp.py:1057-1085) — folded into the word here so that the per-element test is
+// one constant-bit test.
+__device__ __forceinline__ uint32_t flash_open_bits(uint64_t vw, int kt, int g, int dq) {
+  const uint32_t w = (uint32_t)(vw >> (kt * 32)) >> (4 * g);
+  const uint32_t pos = (uint32_t)(dq - 4 * g);  // bit of the query's own key in w (if < 32 and in this lane's groups)
+  return w | ((pos < 32u && !(pos & 4u)) ? (1u << pos) : 0u);
+}
+
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -183,12 +194,10 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
     if (CAUSAL && vw != ~0ull) {  // a tile with padded keys (wave-uniform: most tiles skip this)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
-        const uint32_t w = (uint32_t)(vw >> (kt * 32)) >> (4 * g);
+        const uint32_t w = flash_open_bits(vw, kt, g, qi - (t * 64 + kt * 32));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          if (!((w >> ((r & 3) + 8 * (r >> 2))) & 1u) && key != qi) s[kt][r] = -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r)
+          if (!(w & (1u << ((r & 3) + 8 * (r >> 2))))) s[kt][r] = -INFINITY;
       }
     }
     float mx = -INFINITY;
@@ -341,12 +350,10 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
         }
       }
       if (CAUSAL && vw != ~0ull) {  // padded keys in this tile
-        const uint32_t w = (uint32_t)(vw >> (kt * 32)) >> (4 * g);
+        const uint32_t w = flash_open_bits(vw, kt, g, qi - (t * 64 + kt * 32));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          if (!((w >> ((r & 3) + 8 * (r >> 2))) & 1u) && key != qi) s[r] = -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r)
+          if (!(w & (1u << ((r & 3) + 8 * (r >> 2))))) s[r] = -INFINITY;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

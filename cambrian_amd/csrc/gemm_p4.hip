@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, con
 
     run_stages(cit.nk, relax);
 
+    constexpr uint32_t kEpiStage = 0;  // the ring fills the whole LDS: direct stores
 #include "gemm_p4_epilogue.inc"
     // the cursor is now inside item c_item + stride (nk >= NS is a launch condition): describe the one after it
     const int n2 = c_item + 2 * stride;
@@ -938,6 +939,11 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
     else tile(std::false_type{}, std::integral_constant<int, 0>{});
   };
 
+  if constexpr ((VAR & 1024) != 0) {  // lab probe: phase-shift the workgroups of an XCD by eighths of an item
+    const int phase = ((int)blockIdx.x >> 3) & 7;
+    const int n64 = phase * (p4_item(p, first_item, ntiles).nk >> 1) * 4;  // x 64 cycles: phase * (nt * 2048 / 8) cycles
+    for (int q = 0; q < n64; ++q) asm volatile("s_sleep 1" ::: "memory");
+  }
   bool relax = false;
 #pragma unroll 1
   for (int c_item = first_item; c_item < n_items; c_item += stride) {
@@ -961,6 +967,7 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
       run_tile(false);
     }
 
+    constexpr uint32_t kEpiStage = 2 * kP5Buf;  // 4 x 8 KiB behind the two operand buffers
 #include "gemm_p4_epilogue.inc"
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
@@ -968,7 +975,7 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
 
 template <int ACT, int VAR>
 int launch_p5_act(GemmParams& p, int splits, hipStream_t s) {
-  constexpr int smem = 2 * kP5Buf;
+  constexpr int smem = 2 * kP5Buf + 4 * 8192;  // two operand buffers + the epilogue's staging area = all 160 KiB
   static bool attr_done = false;
   static int n_cu = 0;
   auto kern = gemm_nt_p5_kernel<ACT, VAR>;
@@ -1083,6 +1090,9 @@ int launch_gemm_p5_bf16(GemmParams& p, int splits, int var, hipStream_t s) {
     case 16: return launch_p5_act<CMB_ACT_NONE, 16>(p, splits, s);
     case 17: return launch_p5_act<CMB_ACT_NONE, 17>(p, splits, s);
     case 18: return launch_p5_act<CMB_ACT_NONE, 18>(p, splits, s);
+    case 1024: return p.act == CMB_ACT_GELU_ERF ? launch_p5_act<CMB_ACT_GELU_ERF, 1024>(p, splits, s) : launch_p5_act<CMB_ACT_NONE, 1024>(p, splits, s);
+    case 2048: return p.act == CMB_ACT_GELU_ERF ? launch_p5_act<CMB_ACT_GELU_ERF, 2048>(p, splits, s) : launch_p5_act<CMB_ACT_NONE, 2048>(p, splits, s);
+    case 512: return p.act == CMB_ACT_GELU_ERF ? launch_p5_act<CMB_ACT_GELU_ERF, 512>(p, splits, s) : launch_p5_act<CMB_ACT_NONE, 512>(p, splits, s);
     case 32: return launch_p5_act<CMB_ACT_NONE, 32>(p, splits, s);
     case 34: return launch_p5_act<CMB_ACT_NONE, 34>(p, splits, s);
     case 80: return launch_p5_act<CMB_ACT_NONE, 80>(p, splits, s);
