@@ -162,3 +162,22 @@ def test_gemm_p4_register_epilogue(dev, M, mode, tile):
     out128 = ops.k_gemm(a.to(dev, dt), w.to(dev, dt), tile=128, **kw)
     # same bf16 rounding of the same fp32 values up to the accumulation order: a few bf16 ulps at most
     assert (out.float() - out128.float()).abs().max().item() <= 4e-2 * ref.abs().max().item() * 2 ** -7 * 8
+
+
+def test_default_dispatch_reports_its_kernel(dev):
+    """cmb_gemm_last_kernel: the default picks the 4-wave register-buffered kernel when N is a multiple of 256 and K
+    holds two 64-deep tiles, the 8-wave kernel for a ragged tile column, the 128 tile for small problems; the three
+    agree on the result."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(77)
+    dt = torch.bfloat16
+    outs = {}
+    for (M, N, K), want in [((4096, 1024, 512), 2590), ((4096, 1152, 512), 256), ((4096, 1024, 64), 256), ((64, 64, 64), 128)]:
+        a, w = torch.randn(M, K, generator=g).to(dev, dt), (torch.randn(N, K, generator=g) * 0.2).to(dev, dt)
+        out = ops.k_gemm(a, w)
+        assert L.load().cmb_gemm_last_kernel() == want, (M, N, K, L.load().cmb_gemm_last_kernel())
+        ref = a.float() @ w.float().T
+        assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < 1e-2
+        outs[(M, N, K)] = out
+    a, w = torch.randn(4096, 512, generator=g).to(dev, dt), (torch.randn(1024, 512, generator=g) * 0.2).to(dev, dt)
+    assert torch.equal(ops.k_gemm(a, w, tile=2590), ops.k_gemm(a, w, tile=2560))   # same MFMA order, same rounding
