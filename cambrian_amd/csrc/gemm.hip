@@ -242,7 +242,7 @@ static int tile_override() {
 }
 static bool use_tile256(int M, int N, int splits, int hint) {
   const int ov = hint ? hint : tile_override();
-  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2580 || ov == 2590 || (ov >= 2600 && ov < 5000)) return true;
+  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2580 || ov == 2590 || (ov >= 2600 && ov < 7000)) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -327,7 +327,7 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
       g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
     else if (ov == 2580 && p4_ok(p, splits, 3))
       g_last_kernel = 2580, rc = launch_gemm_p2_bf16(p, splits, s);
-    else if ((ov == 2590 || (ov >= 2700 && ov < 5000) || ((ov == 0 || ov == 256) && p.N % 256 == 0)) &&
+    else if ((ov == 2590 || (ov >= 2700 && ov < 7000) || ((ov == 0 || ov == 256) && p.N % 256 == 0)) &&
              p4_ok(p, splits, 4))  // two 64-deep tiles per item
       g_last_kernel = 2590, rc = launch_gemm_p5_bf16(p, splits, ov >= 2700 ? ov - 2700 : 0, s);
     else if (want_p4 && p4_ok(p, splits, 5))

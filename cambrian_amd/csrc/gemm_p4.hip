@@ -15,12 +15,12 @@
 //     columns: 16-byte bf16 stores, no LDS round trip, no barrier), its stores draining under the next tile's MFMAs.
 //
 // One wave per SIMD means every cycle an LDS / vector-memory instruction spends waiting to be ACCEPTED is a cycle the
-// matrix pipe idles.  Measured (tools/gemm_lab.py, 8192^3): the MFMA stream alone runs 2.04 PFLOP/s; with the four
-// waves issuing their 16 ds_read_b128 per stage in the same cycles it drops to 1.57, with their 8 LDS-DMA pieces to
-// 1.30 — 19 / 74 cycles per instruction, i.e. the four waves queueing on the CU's one LDS and one address unit.  The
-// schedule therefore STAGGERS the waves: wave w issues its reads (in pairs) after MFMA t with t % 4 == w and its DMA
-// pieces after MFMA t with t % 4 == (w + 2) % 4, so in every 32-cycle MFMA slot one wave reads, one wave stages, two
-// only multiply.  The stage body is instantiated per wave (template parameter W) and selected once per tile.
+// matrix pipe idles.  Measured (tools/gemm_lab.py, 8192^3, profiles/r02_gemm_lab.md): the MFMA stream alone runs 1.94-2.04
+// PFLOP/s; with the fragment reads 1.55-1.6; with the LDS-DMA pieces 1.19-1.30.  A per-wave stagger of the issue slots
+// (one wave reads while another stages) was tried and measured nothing; what rides behind each MFMA is therefore the
+// same for all four waves: groups of four slots carrying two reads, the M0 write, one DMA piece, the cursor hand-over.
+// This ring kernel ended within +-7 % of the 8-wave kernel and is opt-in (tile_hint 2570); gemm_nt_p5_kernel further
+// down is the design that came out of its ablations and is the default.
 //
 // Stage g (ring slot g % NS; fragments of the two 16-deep sub-steps ks = 0, 1 live in register sets 0 / 1):
 //     phase A:  16 MFMA on set 0 | reads of (g, ks 1) -> set 1   | DMA pieces 4..7 of stage g + NS - 2 -> slot (g - 2) % NS
@@ -744,13 +744,21 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_p2_kernel(const GemmParams p, 
 // sub-step ks = L >> 4 uses fragment set ks:
 //     L  0..15   one ds_read_b128 per slot: sets 2, 3 <- buffer c
 //     after 17   s_waitcnt lgkmcnt(0); s_barrier (B1)   every wave holds all of tile t: buffer c is free
-//     L 18..48   even slots: LDS-DMA piece (L - 18) / 2 of tile t + 2 -> buffer c  (16 pieces per wave: 8 A, 8 B)
-//     after 49   s_waitcnt vmcnt(16); s_barrier (B2)    tile t + 1 (the 16 pieces before this tile's) has landed
-//     L 50..63   sets 0, 1 <- buffer o (16 reads in 14 slots), cursor + 128 B, buffers swap
+//     L 18..63   every third slot: LDS-DMA piece (L - 18) / 3 of tile t + 2 -> buffer c  (16 pieces per wave: 8 A, 8 B;
+//                a piece every 2 slots measured 3-4 % slower: the four waves' pieces queue on the CU's one address unit)
+//     after 50   s_waitcnt vmcnt(11); s_barrier (B2)    tile t + 1 has landed (the 11 pieces of this tile issued so far
+//                may stay in flight; the 5 that follow are covered by the next tile's wait)
+//     L 51..63   sets 0, 1 <- buffer o (16 reads in 13 slots); after 63: cursor + 128 B, buffers swap
 // Across items: the last two tiles of an item stage the first two tiles of the workgroup's next item (the cursor is
 // re-described two tiles before the end; K >= 128 per item is a launch condition), so the epilogue runs with the
 // next item's tile 0 already in registers and tile 1 in flight.  The first B2 after an epilogue that issued exactly
-// 32 stores waits with vmcnt(16 + 32): the stores are younger than the pieces it needs.
+// 32 stores waits with vmcnt(11 + 32): the stores are younger than the pieces it needs.  The second one cannot be
+// relaxed (tile 2's pieces are younger than the stores): the store acknowledgements are on the critical path there —
+// 11-14 % of a K = 1536 launch (profiles/r02_gemm_lab.md section 5).
+//
+// A piece is "s_add_u32 m0; s_nop 0; global_load_lds_dwordx4": one wait state for M0 and none for the SGPR base, which
+// is only safe while hipcc never reloads that base from a spill slot (v_readlane) within 5 wait states of the piece;
+// check_spills.py walks the assembly of every build and fails it otherwise.
 //
 // LDS buffer: A 256 rows x 128 B then B 256 rows x 128 B, chunk c of row r at r * 128 + ((c ^ gl_swz(r)) << 4)
 // (gemm_layout.h); a DMA piece is 8 rows (8 lanes x 16 B per row), wave w stages rows [64 w, 64 w + 64) of both.
@@ -994,7 +1002,7 @@ int launch_p5_act(GemmParams& p, int splits, hipStream_t s) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   const int n_items = p.tiles_m * p.tiles_n * splits;
-  const int grid = n_items < n_cu ? n_items : n_cu;
+  const int grid = (VAR & 4096) ? n_items : (n_items < n_cu ? n_items : n_cu);  // (4096: lab probe — one item per workgroup)
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, p, n_items);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
@@ -1090,6 +1098,7 @@ int launch_gemm_p5_bf16(GemmParams& p, int splits, int var, hipStream_t s) {
     case 16: return launch_p5_act<CMB_ACT_NONE, 16>(p, splits, s);
     case 17: return launch_p5_act<CMB_ACT_NONE, 17>(p, splits, s);
     case 18: return launch_p5_act<CMB_ACT_NONE, 18>(p, splits, s);
+    case 4096: return p.act == CMB_ACT_GELU_ERF ? launch_p5_act<CMB_ACT_GELU_ERF, 4096>(p, splits, s) : launch_p5_act<CMB_ACT_NONE, 4096>(p, splits, s);
     case 1024: return p.act == CMB_ACT_GELU_ERF ? launch_p5_act<CMB_ACT_GELU_ERF, 1024>(p, splits, s) : launch_p5_act<CMB_ACT_NONE, 1024>(p, splits, s);
     case 2048: return p.act == CMB_ACT_GELU_ERF ? launch_p5_act<CMB_ACT_GELU_ERF, 2048>(p, splits, s) : launch_p5_act<CMB_ACT_NONE, 2048>(p, splits, s);
     case 512: return p.act == CMB_ACT_GELU_ERF ? launch_p5_act<CMB_ACT_GELU_ERF, 512>(p, splits, s) : launch_p5_act<CMB_ACT_NONE, 512>(p, splits, s);
