@@ -270,6 +270,21 @@ static bool p4_ok(const GemmParams& p, int splits, int ns) {
 
 static thread_local int g_last_kernel = 0;  // cmb_gemm_last_kernel()
 
+// Where the register-buffered 4-wave kernel is the default 256 x 256 kernel (measured, profiles/r02_gemm_lab.md): whole
+// tile columns (a ragged one leaves through its generic epilogue and drains the DMA pipeline: N = 1152 runs 20-40 %
+// behind the 8-wave kernel), no pre-activation copy (generic epilogue again), and more than one round of items per CU —
+// its gain is the overlap ACROSS items; a single round with an activation epilogue is 25 % faster on the 8-wave kernel,
+// whose two waves per SIMD interleave the epilogue's dependency chains.
+static bool p5_default(const GemmParams& p, int splits) {
+  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * splits;
+  static long min_tiles = -1;  // CMB_GEMM_P5_MIN_TILES: experiments only
+  if (min_tiles < 0) {
+    const char* e = getenv("CMB_GEMM_P5_MIN_TILES");
+    min_tiles = e ? atol(e) : 257;
+  }
+  return p.N % 256 == 0 && !p.P && tiles >= min_tiles;
+}
+
 template <typename T>
 int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   constexpr int BK = 128 / (int)sizeof(T);
@@ -318,16 +333,15 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
     // 2561 (8-wave kernel, schedule 0 / 1) | 2570 (4-wave ring kernel, gemm_nt_p4_kernel) | 2580 (256x128, two workgroups
     // per CU) | 2590 (gemm_nt_p5_kernel) | 2600 + bits / 2700 + bits (ablations of the ring / p5 kernels, lab builds).
     // Measured on the path's shapes (profiles/r02_gemm_lab.md): p5 is 3-11 % ahead of the 8-wave kernel when N is a
-    // multiple of 256 and up to 40 % behind when it is not (N = 384, 1152: the ragged tile column leaves through the
-    // generic epilogue and drains the DMA pipeline), so the default takes it for N % 256 == 0 only; the ring and the
-    // 256x128 kernels are behind everywhere.
+    // multiple of 256 and up to 40 % behind when it is not (N = 384, 1152), so the default takes it where p5_default()
+    // says; the ring and the 256x128 kernels are behind everywhere.
     const int ov = d->tile_hint ? d->tile_hint : tile_override();
     const bool want_p4 = ov == 2570 || (ov >= 2600 && ov < 2700);
     if (!use_tile256(p.M, p.N, splits, d->tile_hint) || !tile_span_fits_u32(p.a_map, p.ldb))
       g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
     else if (ov == 2580 && p4_ok(p, splits, 3))
       g_last_kernel = 2580, rc = launch_gemm_p2_bf16(p, splits, s);
-    else if ((ov == 2590 || (ov >= 2700 && ov < 7000) || ((ov == 0 || ov == 256) && p.N % 256 == 0)) &&
+    else if ((ov == 2590 || (ov >= 2700 && ov < 7000) || ((ov == 0 || ov == 256) && p5_default(p, splits))) &&
              p4_ok(p, splits, 4))  // two 64-deep tiles per item
       g_last_kernel = 2590, rc = launch_gemm_p5_bf16(p, splits, ov >= 2700 ? ov - 2700 : 0, s);
     else if (want_p4 && p4_ok(p, splits, 5))

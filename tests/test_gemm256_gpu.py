@@ -165,14 +165,15 @@ def test_gemm_p4_register_epilogue(dev, M, mode, tile):
 
 
 def test_default_dispatch_reports_its_kernel(dev):
-    """cmb_gemm_last_kernel: the default picks the 4-wave register-buffered kernel when N is a multiple of 256 and K
-    holds two 64-deep tiles, the 8-wave kernel for a ragged tile column, the 128 tile for small problems; the three
-    agree on the result."""
+    """cmb_gemm_last_kernel: the default picks the 4-wave register-buffered kernel when N is a multiple of 256, K holds
+    two 64-deep tiles and there is more than one round of tiles per CU; the 8-wave kernel for a ragged tile column, K = 64
+    or a single round; the 128 tile for small problems; all agree on the result."""
     ops, L = _ops()
     g = torch.Generator().manual_seed(77)
     dt = torch.bfloat16
     outs = {}
-    for (M, N, K), want in [((4096, 1024, 512), 2590), ((4096, 1152, 512), 256), ((4096, 1024, 64), 256), ((64, 64, 64), 128)]:
+    for (M, N, K), want in [((32768, 2048, 512), 2590), ((32768, 1152, 512), 256), ((32768, 2048, 64), 256), ((8192, 2048, 512), 256),
+                             ((64, 64, 64), 128)]:
         a, w = torch.randn(M, K, generator=g).to(dev, dt), (torch.randn(N, K, generator=g) * 0.2).to(dev, dt)
         out = ops.k_gemm(a, w)
         assert L.load().cmb_gemm_last_kernel() == want, (M, N, K, L.load().cmb_gemm_last_kernel())
