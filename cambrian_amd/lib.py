@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcambrian_amd.so")
+# CAMBRIAN_AMD_LIB: another build of the same C-ABI (same-box A/B runs of two kernel versions); default = the in-tree build
+LIB_PATH = os.environ.get("CAMBRIAN_AMD_LIB") or os.path.join(_HERE, "csrc", "libcambrian_amd.so")
 
 BF16, F32 = 0, 1
 F16 = 2   # output type of cmb_image_preprocess only
