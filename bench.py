@@ -228,6 +228,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    local = int(os.environ.get("CAMBRIAN_BENCH_DEVICE", local))   # (tests: several ranks sharing one GPU over gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import __graft_entry__ as ge

@@ -1,0 +1,32 @@
+"""`-m gpu`: bench.py's N > 1 control flow on a ONE-GPU box — two ranks launched exactly as the driver launches them
+(`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), sharing cuda:0 and exchanging over gloo
+(CAMBRIAN_DIST_BACKEND / CAMBRIAN_BENCH_DEVICE, test-only overrides): rendezvous, the barriers around the timed region,
+GradSync / ZeRO-3 at world size 2 on the real kernels, max-over-ranks timing, one JSON line from rank 0 with the whole-job
+image count.  RCCL itself at N > 1 needs N GPUs (tests/test_dp_gpu.py covers the RCCL call path at world size 1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mode", [[], ["--zero3"]])
+def test_two_ranks_one_json_line(dev, mode):
+    env = dict(os.environ, CAMBRIAN_DIST_BACKEND="gloo", CAMBRIAN_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               CAMBRIAN_AMD_RANDOM_INIT="1")
+    port = 29600 + os.getpid() % 300 + (7 if mode else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--llm-layers", "2", "--no-cpu-baseline", "--no-masked-case"] + mode
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(4 / (d["ms_per_step"] * 1e-3), rel=1e-6)    # whole-job images / max-over-ranks time
+    assert ("zero3" in d["config"]["parallelism"]) == bool(mode)
