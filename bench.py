@@ -394,7 +394,7 @@ def main():
             # with the larger share of the step; the other is reported beside it
             KNAMES = {2590: "cmb_gemm_detail::gemm_nt_p5_kernel (bf16, 256x256x64, 4 waves, fragments of the K tile in registers)",
                       256: "cmb_gemm_detail::gemm_nt_256_kernel (bf16, 256x256x64, 8 waves)",
-                      2570: "cmb_gemm_detail::gemm_nt_p4_kernel", 2580: "cmb_gemm_detail::gemm_nt_p2_kernel"}
+                      2570: "cmb_gemm_detail::gemm_nt_p4_kernel"}
             per = {kid: agg(lambda x, kid=kid: x[3] == torch.bfloat16 and x[5] == 256 and x[7] == kid) for kid in KNAMES}
             dom = max(per, key=lambda kid: per[kid][1])
             f256, ms256, n256 = per[dom]

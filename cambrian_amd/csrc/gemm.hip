@@ -242,7 +242,7 @@ static int tile_override() {
 }
 static bool use_tile256(int M, int N, int splits, int hint) {
   const int ov = hint ? hint : tile_override();
-  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2580 || ov == 2590 || (ov >= 2600 && ov < 7000)) return true;
+  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2590 || (ov >= 2600 && ov < 7000)) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -330,17 +330,14 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // tile_hint / CMB_GEMM_TILE: 0 = cost model (128x128 tile, or a 256x256 tile: the 4-wave register-buffered kernel
     // gemm_nt_p5_kernel where it applies, else the 8-wave kernel) | 128 | 256 (as the cost model's 256 branch) | 2560 /
-    // 2561 (8-wave kernel, schedule 0 / 1) | 2570 (4-wave ring kernel, gemm_nt_p4_kernel) | 2580 (256x128, two workgroups
-    // per CU) | 2590 (gemm_nt_p5_kernel) | 2600 + bits / 2700 + bits (ablations of the ring / p5 kernels, lab builds).
+    // 2561 (8-wave kernel, schedule 0 / 1) | 2570 (4-wave ring kernel, gemm_nt_p4_kernel) | 2590 (gemm_nt_p5_kernel) | 2600 + bits / 2700 + bits (ablations of the ring / p5 kernels, lab builds).
     // Measured on the path's shapes (profiles/r02_gemm_lab.md): p5 is 3-11 % ahead of the 8-wave kernel when N is a
     // multiple of 256 and up to 40 % behind when it is not (N = 384, 1152), so the default takes it where p5_default()
-    // says; the ring and the 256x128 kernels are behind everywhere.
+    // says; the ring kernel is behind everywhere (as was a 256x128 two-workgroups-per-CU design, removed).
     const int ov = d->tile_hint ? d->tile_hint : tile_override();
     const bool want_p4 = ov == 2570 || (ov >= 2600 && ov < 2700);
     if (!use_tile256(p.M, p.N, splits, d->tile_hint) || !tile_span_fits_u32(p.a_map, p.ldb))
       g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
-    else if (ov == 2580 && p4_ok(p, splits, 3))
-      g_last_kernel = 2580, rc = launch_gemm_p2_bf16(p, splits, s);
     else if ((ov == 2590 || (ov >= 2700 && ov < 7000) || ((ov == 0 || ov == 256) && p5_default(p, splits))) &&
              p4_ok(p, splits, 4))  // two 64-deep tiles per item
       g_last_kernel = 2590, rc = launch_gemm_p5_bf16(p, splits, ov >= 2700 ? ov - 2700 : 0, s);

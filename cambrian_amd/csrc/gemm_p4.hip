@@ -396,339 +396,6 @@ __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, con
 
 
 // =====================================================================================================================
-// gemm_nt_p2_kernel — the same persistent structure with TWO workgroups per CU (256 x 128 tile, 4 waves x (128 x 64),
-// 128 accumulator registers, ring of 3 stages = 72 KiB of LDS).  What the probes of the 4-wave kernel say
-// (tools/gemm_lab.py / tools/pmc_variants.sh, 8192^3): the MFMA stream alone runs 1.93-2.04 PFLOP/s, with the
-// fragment reads 1.61, with the staging loads 1.40 — every vector-memory instruction holds its wave's issue port ~60
-// cycles (LDS-DMA, global_load and buffer_load alike; SQ_WAVE_CYCLES +32 cycles per piece = one MFMA slot), and with
-// one wave per SIMD nothing else can issue in that time; the activation epilogue likewise runs at one wave's VALU
-// rate with the matrix pipe idle.  Two independent workgroups per CU put a second wave on every SIMD whose MFMAs fill
-// those holes: one workgroup's staging, barrier waits and WHOLE epilogue overlap the other's multiply phase.
-//
-// Stage g of a workgroup (ring slot g % 3, 24 KiB: A 256 rows x 64 B, B 128 rows x 64 B):
-//     phase A:  8 MFMA on fragment set 0 | 6 reads of (g, ks 1) -> set 1 | cursor hand-over
-//               s_waitcnt vmcnt(0)   stage g + 1 (issued one stage ago) has landed   -> s_barrier
-//     phase B:  8 MFMA on set 1 | 6 reads of (g + 1, ks 0) -> set 0 | the 6 DMA pieces of stage g + 2 -> slot (g - 1) % 3
-// RAW / WAR exactly as in the 4-wave kernel (comment at the top of the file) with the refill one stage closer.
-constexpr int kP2StageA = 256 * 64, kP2StageB = 128 * 64, kP2Stage = kP2StageA + kP2StageB, kP2NS = 3;
-
-__host__ __device__ constexpr int p2_read_order(int n) {  // B0 A0 B1 A1 A2 A3 (MFMA order (i, j) = (t >> 1, t & 1))
-  return n == 0 ? 4 : n == 1 ? 0 : n == 2 ? 5 : n - 2;
-}
-
-__device__ __forceinline__ P4Item p2_item(const GemmParams& p, int item, int ntiles) {
-  P4Item it;
-  const int kz = item / ntiles, lin = item - kz * ntiles;
-  const int id = gl_xcd_remap(lin, ntiles);
-  int tile_m, tile_n;
-  gl_group_tile(id, p.tiles_m, p.tiles_n, 4, &tile_m, &tile_n);  // 64 resident workgroups per XCD = 4 x 16 tiles
-  it.m0 = tile_m * 256;
-  it.n0 = tile_n * 128;
-  it.kz = kz;
-  it.kbeg = kz * p.k_per_split;
-  const int kend = (it.kbeg + p.k_per_split < p.K) ? (it.kbeg + p.k_per_split) : p.K;
-  it.nk = (kend - it.kbeg) / 32;
-  return it;
-}
-
-struct P2Src {
-  uint32_t a_off[4], b_off[2];
-  const char* a_base;
-  const char* b_base;
-  int nk;
-};
-
-template <int ACT>
-__global__ void __launch_bounds__(256, 2) gemm_nt_p2_kernel(const GemmParams p, const int n_items) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef bf16x8_t frag_t;
-  typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, 1> I1;
-  typedef std::integral_constant<int, 2> I2;
-  typedef std::integral_constant<int, 3> I3;
-  typedef std::integral_constant<int, 4> I4;
-  typedef std::integral_constant<int, 5> I5;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int stride = (int)gridDim.x;
-  const int first_item = (int)blockIdx.x;
-  const int last_item = first_item + ((n_items - 1 - first_item) / stride) * stride;
-
-  // ---- DMA side: wave w stages A rows [64 w, 64 w + 64) (4 pieces) and B rows [32 w, 32 w + 32) (2 pieces) ----------
-  const int d_chunk = (lane & 3) ^ ((lane >> 4) & 3);
-  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem));
-  const uint32_t dma_a = lds0 + (uint32_t)wave * 4096u;                       // + slot * kP2Stage + i * 1024
-  const uint32_t dma_b_rel = (uint32_t)kP2StageA + (uint32_t)wave * 2048u - (uint32_t)wave * 4096u;  // relative to dma_a
-  auto src_of = [&](int item) -> P2Src {
-    P2Src r;
-    const P4Item it = p2_item(p, item, ntiles);
-    const int64_t a_row0 = row_off(p.a_map, (uint32_t)it.m0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int gm = it.m0 + wave * 64 + 16 * i + (lane >> 2);
-      gm = gm < p.M ? gm : p.M - 1;
-      r.a_off[i] = (uint32_t)((row_off(p.a_map, (uint32_t)gm) - a_row0) * 2 + d_chunk * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int gn = it.n0 + wave * 32 + 16 * i + (lane >> 2);
-      gn = gn < p.N ? gn : p.N - 1;
-      r.b_off[i] = (uint32_t)((int64_t)(gn - it.n0) * p.ldb * 2 + d_chunk * 16);
-    }
-    r.a_base = p4_uniform_ptr(p.A + (a_row0 + it.kbeg) * 2);
-    r.b_base = p4_uniform_ptr(p.B + ((int64_t)it.n0 * p.ldb + it.kbeg) * 2);
-    r.nk = it.nk;
-    return r;
-  };
-  P2Src cur = src_of(first_item);
-  P2Src nxt = src_of(first_item + stride <= last_item ? first_item + stride : last_item);
-  int dk = 0;
-  bool sw = false;
-  // piece pc (0..3 = A, 4..5 = B) of the cursor's stage into the ring slot whose A region for this wave starts at `dst`.
-  // One statement: M0, the wait states a freshly re-loaded SGPR base needs before a VMEM read (v_readlane of a spill),
-  // the DMA.
-  auto piece = [&](uint32_t dst, auto pc_c) {
-    constexpr int pc = decltype(pc_c)::value;
-    P2Src& c = cur;
-    const uint32_t brel = dma_b_rel;  // (named outside the `if constexpr` arms: see dma_piece of the 4-wave kernel)
-    if constexpr (pc < 4)
-      asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
-                   :
-                   : "v"(c.a_off[pc]), "s"(c.a_base), "s"(dst), "n"(pc * 1024)
-                   : "memory", "m0", "scc");
-    else
-      asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1"
-                   :
-                   : "v"(c.b_off[pc - 4]), "s"(c.b_base), "s"(dst + brel), "n"((pc - 4) * 1024)
-                   : "memory", "m0", "scc");
-  };
-  auto advance = [&](int part) {
-    if (part == 0) {
-      ++dk;
-      sw = (dk == cur.nk);
-      cur.a_base = sw ? nxt.a_base : cur.a_base + 64;
-      cur.b_base = sw ? nxt.b_base : cur.b_base + 64;
-      cur.nk = sw ? nxt.nk : cur.nk;
-      dk = sw ? 0 : dk;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cur.a_off[i] = sw ? nxt.a_off[i] : cur.a_off[i];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) cur.b_off[i] = sw ? nxt.b_off[i] : cur.b_off[i];
-    }
-  };
-
-  // ---- fragment reads --------------------------------------------------------------------------------------------
-  const int f_swz = (lane >> 2) & 3;
-  uint32_t a_rd[2], b_rd[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int koff = ((2 * ks + (lane >> 5)) ^ f_swz) << 4;
-    a_rd[ks] = (uint32_t)((wm * 128 + (lane & 31)) * 64 + koff);
-    b_rd[ks] = (uint32_t)(kP2StageA + (wn * 64 + (lane & 31)) * 64 + koff);
-  }
-  f32x16_t acc[4][2];
-  frag_t fa[2][4], fb[2][2];
-  auto read_frag = [&](int set, uint32_t slot_off, int which) {  // 0..3 = A row block, 4..5 = B column block
-    const char* base = smem + slot_off;
-    if (which < 4) fa[set][which] = *reinterpret_cast<const frag_t*>(base + a_rd[set] + which * 2048);
-    else fb[set][which - 4] = *reinterpret_cast<const frag_t*>(base + b_rd[set] + (which - 4) * 2048);
-  };
-
-  // ---- prologue: stages 0 and 1 ------------------------------------------------------------------------------------
-  asm volatile("s_nop 4" ::: "memory");
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const uint32_t d = dma_a + (uint32_t)st * (uint32_t)kP2Stage;
-    piece(d, I0{}); piece(d, I1{}); piece(d, I2{}); piece(d, I3{}); piece(d, I4{}); piece(d, I5{});
-    if (st == 0) { advance(0); advance(1); }  // (the hand-over behind stage 1 is phase A's, as in steady state)
-  }
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // stage 0 has landed
-  P4_BARRIER();
-
-  uint32_t off_cur = 0, off_next = kP2Stage, dst_fill = dma_a + 2u * kP2Stage;
-  auto stage = [&](auto relax_c) {
-    constexpr bool RELAX = decltype(relax_c)::value;
-    auto extras = [&](auto l_c) {
-      constexpr int L = decltype(l_c)::value;
-      if constexpr (L == 0 || L == 2 || L == 4) {  // reads of (g, ks 1)
-        read_frag(1, off_cur, p2_read_order(L));
-        read_frag(1, off_cur, p2_read_order(L + 1));
-      }
-      if constexpr (L == 1) advance(0);   // the cursor's stage went out in the previous phase B
-      if constexpr (L == 3) advance(1);
-      if constexpr (L == 8) { read_frag(0, off_next, p2_read_order(0)); read_frag(0, off_next, p2_read_order(1)); }
-      if constexpr (L == 11) { read_frag(0, off_next, p2_read_order(2)); read_frag(0, off_next, p2_read_order(3)); }
-      if constexpr (L == 14) { read_frag(0, off_next, p2_read_order(4)); read_frag(0, off_next, p2_read_order(5)); }
-      if constexpr (L == 9) piece(dst_fill, I0{});
-      if constexpr (L == 10) piece(dst_fill, I1{});
-      if constexpr (L == 12) piece(dst_fill, I2{});
-      if constexpr (L == 13) piece(dst_fill, I3{});
-      if constexpr (L == 15) {
-        piece(dst_fill, I4{});
-        piece(dst_fill, I5{});
-        dst_fill = dma_a + off_cur;  // slot g is free after the next barrier
-        off_cur = off_next;
-        off_next = (off_next + kP2Stage == kP2NS * kP2Stage) ? 0u : off_next + kP2Stage;
-      }
-    };
-    auto mfma_at = [&](auto l_c) {
-      constexpr int L = decltype(l_c)::value, t = L & 7, i = t >> 1, j = t & 1, set = L >> 3;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
-      extras(l_c);
-      P4_FENCE();
-    };
-#define P2_M(n) mfma_at(std::integral_constant<int, n>{})
-    P2_M(0); P2_M(1); P2_M(2); P2_M(3); P2_M(4); P2_M(5); P2_M(6); P2_M(7);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAX ? 16 : 0) : "memory");  // stage g + 1 has landed
-    P4_FENCE();
-    P4_BARRIER();
-    P4_FENCE();
-    P2_M(8); P2_M(9); P2_M(10); P2_M(11); P2_M(12); P2_M(13); P2_M(14); P2_M(15);
-#undef P2_M
-  };
-
-  bool relax = false;
-#pragma unroll 1
-  for (int c_item = first_item; c_item < n_items; c_item += stride) {
-    const P4Item cit = p2_item(p, c_item, ntiles);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // the first stage after an epilogue is peeled: its counted wait may leave that epilogue's 16 stores in flight (the
-    // stage it waits for went out before them, in the previous tile's last phase B)
-    // the fragments of a tile's first sub-step are read here rather than carried across the epilogue by the previous
-    // tile's last phase B (24 registers the epilogue needs; the other workgroup covers the latency)
-#pragma unroll
-    for (int w = 0; w < 6; ++w) read_frag(0, off_cur, p2_read_order(w));
-    if (relax) stage(std::true_type{});
-    else stage(std::false_type{});
-#pragma unroll 1
-    for (int k = 1; k < cit.nk; ++k) stage(std::false_type{});
-
-    // ---- epilogue straight from the accumulators (see the 4-wave kernel for the reasoning behind each asm) ----------
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    int e_lane = lane;
-    asm volatile("" : "+v"(e_lane));
-    const int half = e_lane >> 5;
-    const bool upper = half != 0;
-    const int gn0 = cit.n0 + wn * 64 + 8 * half;  // + 16 g4, g4 = 2 j + pr
-    auto take8 = [&](auto i_c, auto g_c, float (&v)[8]) {
-      constexpr int i = decltype(i_c)::value, g4 = decltype(g_c)::value, j = g4 >> 1, pr = g4 & 1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        uint32_t lo, hi;
-        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3\n\ts_nop 1"
-                     : "=&v"(lo), "=&v"(hi)
-                     : "a"(acc[i][j][8 * pr + e]), "a"(acc[i][j][8 * pr + 4 + e]));
-        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
-        v[e] = __uint_as_float(r[0]);
-        v[4 + e] = __uint_as_float(r[1]);
-      }
-    };
-    const bool rows_all = cit.m0 + wm * 128 + 128 <= p.M;
-    const bool fast = !p.slabs && !p.out_f32 && !p.a_scale && !p.b_scale && !p.P && cit.n0 + 128 <= p.N &&
-                      (!p.R || rows_all);
-    relax = fast && rows_all;  // exactly 16 stores behind the DMA pieces the next stage waits for
-    if (fast) {
-      const float* bias_w = p.bias ? p.bias + cit.n0 + wn * 64 : nullptr;
-      const float* cs_w = p.colscale ? p.colscale + cit.n0 + wn * 64 : nullptr;
-      int64_t crow[4];
-      bool okr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
-        okr[i] = gm < p.M;
-        crow[i] = row_off(p.c_map, (uint32_t)(okr[i] ? gm : p.M - 1)) + gn0;
-      }
-      auto body = [&](auto h_c, auto r_c) {  // column groups g = 2 h, 2 h + 1
-        constexpr int h = decltype(h_c)::value;
-        constexpr bool HAS_R = decltype(r_c)::value;
-        bf16x8_t res[4][2];
-        if constexpr (HAS_R) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
-            const bf16_t* rrow = reinterpret_cast<const bf16_t*>(p.R) + row_off(p.r_map, (uint32_t)gm) + gn0;
-#pragma unroll
-            for (int gl = 0; gl < 2; ++gl)
-              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(res[i][gl]) : "v"(rrow + 16 * (2 * h + gl)) : "memory");
-          }
-        }
-        auto group = [&](auto gl_c) {
-          constexpr int gl = decltype(gl_c)::value, g = 2 * h + gl;
-          float bias[8], cs[8];
-          if (bias_w) p4_colvec(bias_w + 16 * g, upper, bias);
-          if (cs_w) p4_colvec(cs_w + 16 * g, upper, cs);
-          auto row = [&](auto i_c) {
-            constexpr int i = decltype(i_c)::value;
-            float v[8];
-            take8(i_c, std::integral_constant<int, g>{}, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-            if (bias_w) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += bias[e];
-            }
-            if constexpr (ACT == CMB_ACT_GELU_ERF) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = cmb_gelu_erf_fast(v[e]);
-            } else if constexpr (ACT != CMB_ACT_NONE) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);
-            }
-            if (cs_w) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= cs[e];
-            }
-            if constexpr (HAS_R) {
-              // load 2 i + gl of this half; behind it 7 - (2 i + gl) loads and the 4 gl + i stores of this half so far
-              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(res[i][gl]) : "n"(7 - i + 3 * gl));
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)res[i][gl][e];
-            }
-            if (okr[i])
-              *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16_t*>(p.C) + crow[i] + 16 * g) =
-                  cvt8_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-            P4_FENCE();
-          };
-          row(I0{}); row(I1{}); row(I2{}); row(I3{});
-        };
-        group(I0{}); group(I1{});
-      };
-      if (p.R) {
-        body(I0{}, std::true_type{});
-        body(I1{}, std::true_type{});
-      } else {
-        body(I0{}, std::false_type{});
-        body(I1{}, std::false_type{});
-      }
-    } else {
-      auto slow = [&](auto i_c, auto g_c) {
-        constexpr int i = decltype(i_c)::value, g = decltype(g_c)::value;
-        float v[8];
-        take8(i_c, g_c, v);
-        const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane & 31);
-        const int gn = gn0 + 16 * g;
-        if (gm < p.M && gn < p.N) gemm_epilogue8<bf16_t, ACT>(p, cit.kz, gm, gn, v);
-        P4_FENCE();
-      };
-      auto slow_row = [&](auto i_c) { slow(i_c, I0{}); slow(i_c, I1{}); slow(i_c, I2{}); slow(i_c, I3{}); };
-      slow_row(I0{}); slow_row(I1{}); slow_row(I2{}); slow_row(I3{});
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): retire the helper's loads for hipcc's scoreboard
-    }
-    const int n2 = c_item + 2 * stride;
-    nxt = src_of(n2 <= last_item ? n2 : last_item);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// =====================================================================================================================
 // gemm_nt_p5_kernel — the 4-wave persistent kernel with 64-deep K tiles, the WHOLE tile's fragments held in registers
 // and a two-buffer LDS (2 x 64 KiB).  Differences from gemm_nt_p4_kernel and why (profiles/r02_gemm_lab.md):
 //   * a stage row is 128 B = one full cache line per tile row (the 32-deep stages of the ring fetch every line of A
@@ -1035,33 +702,6 @@ int launch_p5_act(GemmParams& p, int splits, hipStream_t s) {
   return CMB_OK;
 }
 
-template <int ACT>
-int launch_p2_act(GemmParams& p, int splits, hipStream_t s) {
-  constexpr int smem = kP2NS * kP2Stage;
-  static bool attr_done = false;
-  static int n_cu = 0;
-  auto kern = gemm_nt_p2_kernel<ACT>;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess)
-      return CMB_ERR_LAUNCH;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-      return CMB_ERR_LAUNCH;
-    n_cu -= n_cu % 8;
-    if (n_cu <= 0) return CMB_ERR_LAUNCH;
-    attr_done = true;
-  }
-  p.tiles_m = (p.M + 255) / 256;
-  p.tiles_n = (p.N + 127) / 128;
-  const int n_items = p.tiles_m * p.tiles_n * splits;
-  const int grid = n_items < 2 * n_cu ? n_items : 2 * n_cu;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, p, n_items);
-  CMB_CHECK_LAUNCH();
-  return CMB_OK;
-}
-
 template <int ACT, int NS, int VAR>
 int launch_p4_act(GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem = NS * kP4Stage;
@@ -1101,16 +741,6 @@ int launch_p4_ns(GemmParams& p, int splits, hipStream_t s) {
 }
 
 }  // namespace
-
-int launch_gemm_p2_bf16(GemmParams& p, int splits, hipStream_t s) {
-  switch (p.slabs ? CMB_ACT_NONE : p.act) {
-    case CMB_ACT_GELU_ERF: return launch_p2_act<CMB_ACT_GELU_ERF>(p, splits, s);
-    case CMB_ACT_GELU_TANH: return launch_p2_act<CMB_ACT_GELU_TANH>(p, splits, s);
-    case CMB_ACT_QUICK_GELU: return launch_p2_act<CMB_ACT_QUICK_GELU>(p, splits, s);
-    case CMB_ACT_SILU: return launch_p2_act<CMB_ACT_SILU>(p, splits, s);
-    default: return launch_p2_act<CMB_ACT_NONE>(p, splits, s);
-  }
-}
 
 int launch_gemm_p5_bf16(GemmParams& p, int splits, int var, hipStream_t s) {
 #ifdef CMB_GEMM_LAB

@@ -93,8 +93,8 @@ typedef struct cmb_gemm_desc {
   void* workspace; int64_t workspace_bytes;
   int32_t tile_hint;       /* 0 = choose by grid-fill cost model; 128 / 256 = force that block tile (bf16 only);
                               2560 / 2561 = 256 tile with schedule 0 (8-phase ping-pong, default) / 1 (in-wave pipeline);
-                              2570 = persistent 4-wave 256x256 kernel, 2580 = persistent 256x128 kernel with two workgroups
-                              per CU (gemm_p4.hip; opt-in experimental configurations, same results) */
+                              2590 = 4-wave register-buffered 256x256 kernel (what 0 / 256 pick when N % 256 == 0 and there is
+                              more than one round of tiles), 2570 = its ring-of-stages predecessor (gemm_p4.hip; same results) */
   const float* a_scale;    /* CMB_FP8_E4M3 only: [M] fp32 dequantisation factor of each A row (or NULL = 1) */
   const float* b_scale;    /* CMB_FP8_E4M3 only: [N] fp32 dequantisation factor of each B row (or NULL = 1);
                               the accumulator is multiplied by a_scale[m] * b_scale[n] before alpha / bias */
@@ -112,7 +112,7 @@ int cmb_quantize_fp8_rows(int dtype, const void* x, int64_t ldx, int64_t rows, i
 int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint);
 /* which kernel the calling thread's most recent cmb_gemm launched (0 before the first): 128 = 128x128 tile kernel,
  * 256 = 8-wave 256x256 kernel (gemm256.hip), 2590 = 4-wave register-buffered 256x256 kernel (gemm_nt_p5_kernel),
- * 2570 / 2580 = the opt-in persistent ring / 256x128 kernels.  For labelling profiles and rooflines per kernel. */
+ * 2570 = the opt-in persistent ring kernel.  For labelling profiles and rooflines per kernel. */
 int cmb_gemm_last_kernel(void);
 
 /* out[C, R_pad] = in[R, C]^T, zero-filling columns R..R_pad-1 (R_pad >= R). Used to put the

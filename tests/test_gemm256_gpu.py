@@ -25,9 +25,9 @@ SHAPES = [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 512, 256), (30
 
 
 # tile_hint: 256x256 tile; 2560 / 2561 = 8-wave kernel, schedule 0 (8-phase ping-pong) / 1 (in-wave pipeline, 1 barrier
-# per K-tile); 2570 = persistent 4-wave kernel (256 x 256 tile, ring of 5 stages); 2580 = persistent 256 x 128 tile, two
-# workgroups per CU (ring of 3 stages)
-SCHEDS = [2560, 2561, 2570, 2580, 2590]
+# per K-tile); 2570 = persistent 4-wave kernel (256 x 256 tile, ring of 5 stages); 2590 = the 4-wave register-buffered kernel
+# (two LDS buffers, the K tile's fragments in registers: the default where it applies)
+SCHEDS = [2560, 2561, 2570, 2590]
 
 
 @pytest.mark.parametrize("tile", SCHEDS)
@@ -126,7 +126,7 @@ def test_gemm256_rowmaps(dev, tile):
     assert torch.equal(hd.cpu()[mask], hidden[mask])   # untouched rows bit-identical
 
 
-@pytest.mark.parametrize("tile", [2570, 2580, 2590])
+@pytest.mark.parametrize("tile", [2570, 2590])
 @pytest.mark.parametrize("mode", ["plain", "bias_gelu", "bias_silu", "bias_cs_res", "res", "cs"])
 @pytest.mark.parametrize("M", [1024, 1000, 2300])
 def test_gemm_p4_register_epilogue(dev, M, mode, tile):
