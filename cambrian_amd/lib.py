@@ -107,6 +107,8 @@ SIGNATURES = {
     "cmb_sva_attn_bwd": (C.c_int, [C.POINTER(SvaDesc), _p]),
     "cmb_embed_splice_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p]),
     "cmb_embed_splice_bwd": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _i64, _i32, _p, _p, _p]),
+    "cmb_sva_fold_kv_fwd": (C.c_int, [_p] * 6 + [_i64, _i64, _p, _p, _p]),
+    "cmb_sva_fold_kv_bwd": (C.c_int, [_p] * 8 + [_i64, _i64] + [_p] * 7),
     "cmb_token_mean_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_token_mean_bwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_vit_attn_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i32, _i32, _f, _p, _i32, _p]),

@@ -26,6 +26,7 @@ from .. import lib as L
 from .. import ops
 
 
+
 class MLP(nn.Module):
     """vision_sampler.py:237-245 (no biases, exact-erf GELU)."""
 
@@ -68,11 +69,7 @@ class MultiKVCrossAttention(nn.Module):
     def folded_kv(self, i: int):
         """[Wk*gk ; Wv*gv] ([2*hidden, kv_dim]) and [Wk@bk ; Wv@bv] ([2*hidden]) in fp32 (autograd-tracked)."""
         kp, vp = getattr(self, f"k_proj_{i}"), getattr(self, f"v_proj_{i}")
-        wk = kp[1].weight.float() * kp[0].weight.float()[None, :]
-        wv = vp[1].weight.float() * vp[0].weight.float()[None, :]
-        bk = kp[1].weight.float() @ kp[0].bias.float()
-        bv = vp[1].weight.float() @ vp[0].bias.float()
-        return torch.cat([wk, wv], dim=0), torch.cat([bk, bv], dim=0)
+        return ops.fold_kv(kp[1].weight, kp[0].weight, kp[0].bias, vp[1].weight, vp[0].weight, vp[0].bias)
 
     def forward(self, queries, *vision_latents_attention_mask_list):
         raise RuntimeError("MultiKVCrossAttention is driven by VisionCrossAttentionLayer on the HIP path")

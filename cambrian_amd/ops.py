@@ -585,6 +585,45 @@ def sva_norm(x, pos, holder, side, grid_r, eps=1e-5):
 
 
 # ================================================================================================
+# autograd: K|V weight folding of one tower (vision_sampler.py:173-174,188-189)
+# ================================================================================================
+class FoldKVFn(torch.autograd.Function):
+    """(Wk, gk, bk, Wv, gv, bv) -> ([Wk*gk ; Wv*gv] [2H, K], [Wk@bk ; Wv@bv] [2H]) in fp32, two HIP launches per step."""
+
+    @staticmethod
+    def forward(ctx, wk, gk, bk, wv, gv, bv):
+        ts = [t.detach().contiguous() for t in (wk, gk, bk, wv, gv, bv)]
+        for t in ts:
+            L.require_gpu(t)
+            if t.dtype != torch.float32:
+                raise L.CambrianAmdError("fold_kv: fp32 master parameters expected")
+        H, K = ts[0].shape
+        w = torch.empty((2 * H, K), dtype=torch.float32, device=ts[0].device)
+        b = torch.empty((2 * H,), dtype=torch.float32, device=ts[0].device)
+        rc = L.load().cmb_sva_fold_kv_fwd(*[t.data_ptr() for t in ts], H, K, w.data_ptr(), b.data_ptr(), L.stream_ptr(w.device))
+        L.check(rc, "cmb_sva_fold_kv_fwd")
+        ctx.save_for_backward(*ts)
+        return w, b
+
+    @staticmethod
+    def backward(ctx, dw, db):
+        ts = ctx.saved_tensors
+        H, K = ts[0].shape
+        dev = ts[0].device
+        dw = torch.zeros((2 * H, K), dtype=torch.float32, device=dev) if dw is None else dw.contiguous().float()
+        db = torch.zeros((2 * H,), dtype=torch.float32, device=dev) if db is None else db.contiguous().float()
+        outs = [torch.empty_like(t) for t in ts]
+        rc = L.load().cmb_sva_fold_kv_bwd(dw.data_ptr(), db.data_ptr(), *[t.data_ptr() for t in ts], H, K,
+                                          *[o.data_ptr() for o in outs], L.stream_ptr(dev))
+        L.check(rc, "cmb_sva_fold_kv_bwd")
+        return tuple(outs)
+
+
+def fold_kv(wk, gk, bk, wv, gv, bv):
+    return FoldKVFn.apply(wk, gk, bk, wv, gv, bv)
+
+
+# ================================================================================================
 # autograd: SVA attention core
 # ================================================================================================
 class SvaAttnFn(torch.autograd.Function):

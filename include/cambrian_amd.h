@@ -229,6 +229,17 @@ int cmb_embed_splice_fwd(int dtype, const int64_t* ids, int64_t B, int64_t S, in
 int cmb_embed_splice_bwd(int dtype, const void* dout, const int32_t* pos, int64_t B, int64_t S,
                          int64_t H, int32_t side, void* dfeat, float* dnewline, void* stream);
 
+/* K|V weight folding of one tower of one SVA layer (vision_sampler.py:173-174,188-189: k_proj_i / v_proj_i = LayerNorm ->
+ * Linear; the two LayerNorms share their statistics, so their affines are folded into one projection):
+ *   w_out[n,:] = W[n,:] * gamma,  b_out[n] = W[n,:] . beta;  rows 0..H-1 from (wk, gk, bk), rows H..2H-1 from (wv, gv, bv).
+ * All fp32 (master parameters); wk / wv [H, K] row-major, K % 4 == 0.  bwd: given d(w_out) [2H, K] and d(b_out) [2H]
+ * writes dW = dw * gamma + db (x) beta, dgamma = colsum(dw o W), dbeta = W^T db for both halves.  Deterministic. */
+int cmb_sva_fold_kv_fwd(const float* wk, const float* gk, const float* bk, const float* wv, const float* gv, const float* bv,
+                        int64_t H, int64_t K, float* w_out, float* b_out, void* stream);
+int cmb_sva_fold_kv_bwd(const float* dw_out, const float* db_out, const float* wk, const float* gk, const float* bk,
+                        const float* wv, const float* gv, const float* bv, int64_t H, int64_t K, float* dwk, float* dgk,
+                        float* dbk, float* dwv, float* dgv, float* dbv, void* stream);
+
 /* mean over tokens: out[b,:] = mean_t x[b,t,:]  (cambrian_arch.py:377); bwd broadcasts. */
 int cmb_token_mean_fwd(int dtype, const void* x, int64_t B, int64_t T, int64_t D, void* out,
                        void* stream);

@@ -109,3 +109,31 @@ def test_cpu_tensor_has_no_fallback():
     q = torch.zeros(2, 1, 1024)
     with pytest.raises(CambrianAmdError):
         m(q, q, q, torch.ones(2, 1, dtype=torch.bool))
+
+
+@pytest.mark.parametrize("H,K", [(1024, 1024), (64, 36), (130, 512)])
+def test_fold_kv_matches_the_torch_expression(dev, H, K):
+    """cmb_sva_fold_kv_fwd / _bwd (two launches) against the expression they replace (vision_sampler.py:173-174,188-189
+    with the LayerNorm affines folded): [Wk*gk ; Wv*gv], [Wk@bk ; Wv@bv] and all six gradients, fp32."""
+    from cambrian_amd import ops
+    g = torch.Generator().manual_seed(H + K)
+    ts = [torch.randn(H, K, generator=g), torch.randn(K, generator=g), torch.randn(K, generator=g),
+          torch.randn(H, K, generator=g), torch.randn(K, generator=g), torch.randn(K, generator=g)]
+    a = [t.clone().to(dev).requires_grad_() for t in ts]
+    b = [t.clone().double().requires_grad_() for t in ts]
+    w, bias = ops.fold_kv(*a)
+    wr = torch.cat([b[0] * b[1][None, :], b[3] * b[4][None, :]], 0)
+    br = torch.cat([b[0] @ b[2], b[3] @ b[5]], 0)
+    assert rel_err(w, wr.float()) < 1e-6 and rel_err(bias, br.float()) < 1e-5
+    gw, gb = torch.randn(2 * H, K, generator=g), torch.randn(2 * H, generator=g)
+    (w * gw.to(dev)).sum().backward(retain_graph=True)
+    (bias * gb.to(dev)).sum().backward()
+    ((wr * gw.double()).sum() + (br * gb.double()).sum()).backward()
+    for x, y in zip(a, b):
+        assert rel_err(x.grad, y.grad.float()) < 2e-5, (x.shape, rel_err(x.grad, y.grad.float()))
+    # deterministic: a second backward gives the same bits
+    a2 = [t.clone().to(dev).requires_grad_() for t in ts]
+    w2, b2 = ops.fold_kv(*a2)
+    ((w2 * gw.to(dev)).sum() + (b2 * gb.to(dev)).sum()).backward()
+    w3, b3 = ops.fold_kv(*[t.clone().to(dev).requires_grad_() for t in ts])
+    assert torch.equal(w2, w3) and torch.equal(b2, b3)
