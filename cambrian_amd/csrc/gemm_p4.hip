@@ -423,9 +423,11 @@ __global__ void __launch_bounds__(256) gemm_nt_p4_kernel(const GemmParams p, con
 // Across items: the last two tiles of an item stage the first two tiles of the workgroup's next item (the cursor is
 // re-described two tiles before the end; K >= 128 per item is a launch condition), so the epilogue runs with the
 // next item's tile 0 already in registers and tile 1 in flight.  The first B2 after an epilogue that issued exactly
-// 32 stores waits with vmcnt(14 + 32): the stores are younger than the pieces it needs.  The second one cannot be
-// relaxed (tile 2's pieces are younger than the stores): the store acknowledgements are on the critical path there —
-// 11-14 % of a K = 1536 launch (profiles/r02_gemm_lab.md section 5).
+// 32 stores waits with vmcnt(14 + 32): the stores are younger than the pieces it needs (a two-instruction uniform branch
+// around the s_waitcnt — two copies of the tile body selected at run time cost the register allocator ~500 spills).  The
+// second tile's wait cannot be relaxed (tile 2's pieces are younger than the stores).  Splitting the first tile around the
+// previous item's epilogue, so that tile 2's pieces go out BEFORE the stores, was built and measured: 0 to -6 % (the
+// front's 16 reads + 16 pieces run with the matrix pipe idle), so it is not here (profiles/r02_gemm_lab.md section 5).
 //
 // A piece is "s_add_u32 m0; s_nop 0; global_load_lds_dwordx4": one wait state for M0 and none for the SGPR base, which
 // is only safe while hipcc never reloads that base from a spill slot (v_readlane) within 5 wait states of the piece;
@@ -573,8 +575,10 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
   constexpr int kStep = (VAR & 32) ? 2 : 3;  // MFMA slots between two DMA pieces
   constexpr bool kSplit = (VAR & 16) == 0;   // the A half of a buffer is handed back before the B half has been read (16: lab, one hand-over)
   constexpr int kB1 = 17, kB2 = kB1 + 33, kTail = 63 - kB2, kDouble = 16 - kTail;
-  auto tile = [&](auto relax_c, auto ph_c) __attribute__((always_inline)) {
-    constexpr bool RELAX = decltype(relax_c)::value;
+  // rl: the tile's counted wait may leave 32 more operations (an epilogue's stores) in flight; a two-instruction uniform
+  // branch around the s_waitcnt, NOT a second copy of the tile body (two copies selected at run time cost the register
+  // allocator hundreds of spills)
+  auto tile = [&](bool rl, auto ph_c) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_c)::value, P0 = kB1 + 1 + PH;
     auto extras = [&](auto l_c) {
       constexpr int L = decltype(l_c)::value;
@@ -595,7 +599,8 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
         if constexpr (L >= 34 && L <= 55 && ((L - 34) % 3) == 0 && !kNoDma)   // B-row pieces 8..15
           piece(dma_lds + off_c, std::integral_constant<int, 8 + (L - 34) / 3>{});
         if constexpr (L == kB2) {  // 8 A + 6 B pieces of this tile may stay in flight
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(14 + (RELAX ? 32 : 0)) : "memory");
+          if (rl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(14 + 32) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(14) : "memory");
           P4_BARRIER();
         }
       } else {
@@ -608,7 +613,8 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
         piece(dma_lds + off_c, std::integral_constant<int, (L - P0) / kStep>{});
       if constexpr (L == kB2) {  // the pieces of this tile issued so far may stay in flight
         constexpr int mine = (kB2 - P0) / kStep + 1 > 16 ? 16 : (kB2 - P0) / kStep + 1;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(mine + (RELAX ? 32 : 0)) : "memory");
+        if (rl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(mine + 32) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(mine) : "memory");
         P4_BARRIER();
       }
       }
@@ -636,10 +642,7 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
 #undef P5_M8
 #undef P5_M
   };
-  auto run_tile = [&](bool rl) __attribute__((always_inline)) {
-    if (rl) tile(std::true_type{}, std::integral_constant<int, 0>{});
-    else tile(std::false_type{}, std::integral_constant<int, 0>{});
-  };
+  auto run_tile = [&](bool rl) __attribute__((always_inline)) { tile(rl, std::integral_constant<int, 0>{}); };
 
   if constexpr ((VAR & 1024) != 0) {  // lab probe: phase-shift the workgroups of an XCD by eighths of an item
     const int phase = ((int)blockIdx.x >> 3) & 7;
@@ -647,6 +650,7 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
     for (int q = 0; q < n64; ++q) asm volatile("s_sleep 1" ::: "memory");
   }
   bool relax = false;
+  constexpr uint32_t kEpiStage = 2 * kP5Buf;  // 4 x 8 KiB behind the two operand buffers
 #pragma unroll 1
   for (int c_item = first_item; c_item < n_items; c_item += stride) {
     const P4Item cit = p4_item(p, c_item, ntiles);
@@ -669,7 +673,6 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
       run_tile(false);
     }
 
-    constexpr uint32_t kEpiStage = 2 * kP5Buf;  // 4 x 8 KiB behind the two operand buffers
 #include "gemm_p4_epilogue.inc"
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
