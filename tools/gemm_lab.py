@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--quick", action="store_true")
-ap.add_argument("--variants", default="128,2560,2570,2574,blas")
+ap.add_argument("--variants", default="128,2560,2590,blas")
 ap.add_argument("--shapes", default="")
 args = ap.parse_args()
 
