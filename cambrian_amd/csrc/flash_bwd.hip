@@ -119,7 +119,9 @@ __device__ __forceinline__ void tile_put(const TileRegs& r, bf16_t* sR, bf16_t* 
 // accumulator -> operand without shuffles and V^T fragments from the transposed V image.  K/V heads are shared by the
 // query heads of a group without being expanded.  Writes O (bf16) and lse = log sum_j exp(scale q.k_j) (fp32).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+// MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
+// registers or code (with a run-time pointer test instead they ran 3-8 % slower although every tile took the all-valid path).
+template <bool CAUSAL, bool MASKED>
 __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse_out) {
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
@@ -153,20 +155,20 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
   TileRegs rk, rv;
   tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
   tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
-  uint8_t vb = CAUSAL ? kv_byte(p, b, 0, lane) : (uint8_t)1;  // key-padding byte of this lane's key of the NEXT tile
+  uint8_t vb = MASKED ? kv_byte(p, b, 0, lane) : (uint8_t)1;  // key-padding byte of this lane's key of the NEXT tile
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // previous tile consumed
     tile_put<true, false>(rk, sK, nullptr, tid);
     tile_put<false, true>(rv, nullptr, sVT, tid);
     __syncthreads();
-    const uint64_t vw = CAUSAL ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;  // validity of this tile's 64 keys
+    const uint64_t vw = MASKED ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;  // validity of this tile's 64 keys
     if (t + 1 < nt) {  // the next tile's loads fly during this tile's MFMAs
       tile_load(rk, kbase, p.kv_ss, (t + 1) * 64, p.S, tid);
       tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
-      if (CAUSAL) vb = kv_byte(p, b, t + 1, lane);
+      if (MASKED) vb = kv_byte(p, b, t + 1, lane);
     }
     if (CAUSAL && t * 64 > q0 + 31) continue;
-    if (CAUSAL && vw == 0 && t * 64 + 63 < q0) continue;  // a tile of padding below the wave's diagonal: nothing to add
+    if (MASKED && vw == 0 && t * 64 + 63 < q0) continue;  // a tile of padding below the wave's diagonal: nothing to add
     f32x16_t s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
           if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[kt][r] = -INFINITY;
         }
     }
-    if (CAUSAL && vw != ~0ull) {  // a tile with padded keys (wave-uniform: most tiles skip this)
+    if (MASKED && vw != ~0ull) {  // a tile with padded keys (wave-uniform: most tiles skip this)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
         const uint32_t w = flash_open_bits(vw, kt, g, qi - (t * 64 + kt * 32));
@@ -260,7 +262,9 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
 // ------------------------------------------------------------------------------------------------------------------
 // dQ: grid S/128 * H * B (1-D, flash_block_qh), 256 threads.  lane = (query j = lane & 31 of the wave's 32, half g = lane >> 5).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+// MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
+// registers or code (with a run-time pointer test instead they ran 3-8 % slower although every tile took the all-valid path).
+template <bool CAUSAL, bool MASKED>
 __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const FlashParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
   __shared__ __attribute__((aligned(16))) bf16_t sV[64 * LDR];
@@ -315,20 +319,20 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
   TileRegs rk, rv;
   tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
   tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
-  uint8_t vb = CAUSAL ? kv_byte(p, b, 0, lane) : (uint8_t)1;
+  uint8_t vb = MASKED ? kv_byte(p, b, 0, lane) : (uint8_t)1;
   for (int t = 0; t < nt; ++t) {
     __syncthreads();  // previous tile fully consumed
     tile_put<true, true>(rk, sK, sKT, tid);
     tile_put<true, false>(rv, sV, nullptr, tid);
     __syncthreads();
-    const uint64_t vw = CAUSAL ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
+    const uint64_t vw = MASKED ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
     if (t + 1 < nt) {  // the next tile's loads fly during this tile's MFMAs
       tile_load(rk, kbase, p.kv_ss, (t + 1) * 64, p.S, tid);
       tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
-      if (CAUSAL) vb = kv_byte(p, b, t + 1, lane);
+      if (MASKED) vb = kv_byte(p, b, t + 1, lane);
     }
     if (CAUSAL && t * 64 > q0 + 31) continue;  // whole tile above this wave's diagonal (block-uniform barriers stay matched)
-    if (CAUSAL && vw == 0 && t * 64 + 63 < q0) continue;  // padding only, below the diagonal
+    if (MASKED && vw == 0 && t * 64 + 63 < q0) continue;  // padding only, below the diagonal
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16_t s, dp;
@@ -349,7 +353,7 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
           if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[r] = -INFINITY;   // exp2(-inf) = 0
         }
       }
-      if (CAUSAL && vw != ~0ull) {  // padded keys in this tile
+      if (MASKED && vw != ~0ull) {  // padded keys in this tile
         const uint32_t w = flash_open_bits(vw, kt, g, qi - (t * 64 + kt * 32));
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -396,7 +400,9 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
 // workgroup by a register prefetch (see the loop).  (A double-buffered-LDS variant with one barrier per tile measured
 // slower: 506 registers, values shuffled through the accumulator file.)
 // ------------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+// MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
+// registers or code (with a run-time pointer test instead they ran 3-8 % slower although every tile took the all-valid path).
+template <bool CAUSAL, bool MASKED>
 __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);   // [64][LDR]
@@ -428,8 +434,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   }
   const float c2 = p.scale * LOG2E;
   // key-padding mask: this lane's key is padded -> only its own query (the open diagonal) contributes
-  const bool kvalid = !CAUSAL || !p.key_valid || p.key_valid[(int64_t)b * p.S + ki] != 0;
-  const bool wave_padded = __builtin_amdgcn_ballot_w64(!kvalid) != 0;
+  const bool kvalid = !MASKED || p.key_valid[(int64_t)b * p.S + ki] != 0;
+  const bool wave_padded = MASKED && __builtin_amdgcn_ballot_w64(!kvalid) != 0;
   f32x16_t adk[DT], adv[DT];
 #pragma unroll
   for (int d = 0; d < DT; ++d)
@@ -593,19 +599,24 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<false>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return CMB_ERR_LAUNCH;
     attr_done = true;
   }
-  if (causal) {
-    hipLaunchKernelGGL(flash_dq_kernel<true>, gq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(flash_dkdv_kernel<true>, gk, dim3(256), smem, s, p);
+  if (causal && p.key_valid) {
+    hipLaunchKernelGGL((flash_dq_kernel<true, true>), gq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((flash_dkdv_kernel<true, true>), gk, dim3(256), smem, s, p);
+  } else if (causal) {
+    hipLaunchKernelGGL((flash_dq_kernel<true, false>), gq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((flash_dkdv_kernel<true, false>), gk, dim3(256), smem, s, p);
   } else {
-    hipLaunchKernelGGL(flash_dq_kernel<false>, gq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(flash_dkdv_kernel<false>, gk, dim3(256), smem, s, p);
+    hipLaunchKernelGGL((flash_dq_kernel<false, false>), gq, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((flash_dkdv_kernel<false, false>), gk, dim3(256), smem, s, p);
   }
   CMB_CHECK_LAUNCH();
   return CMB_OK;
@@ -628,10 +639,12 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.key_valid = causal ? key_valid : nullptr;
   const int64_t nqb = S / 128;
   const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal != 0) * H * B));   // 1-D: flash_map.h
-  if (causal)
-    hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
+  if (causal && p.key_valid)
+    hipLaunchKernelGGL((flash_fwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
+  else if (causal)
+    hipLaunchKernelGGL((flash_fwd_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
   else
-    hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
+    hipLaunchKernelGGL((flash_fwd_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }
