@@ -2,7 +2,7 @@
 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), sharing cuda:0 and exchanging over gloo
 (CAMBRIAN_DIST_BACKEND / CAMBRIAN_BENCH_DEVICE, test-only overrides): rendezvous, the barriers around the timed region,
 GradSync / ZeRO-3 at world size 2 on the real kernels, max-over-ranks timing, one JSON line from rank 0 with the whole-job
-image count.  RCCL itself at N > 1 needs N GPUs (tests/test_dp_gpu.py covers the RCCL call path at world size 1)."""
+image count.  (Named zz: it spawns processes and a rendezvous, so it runs last under `pytest -x`.)  RCCL itself at N > 1 needs N GPUs (tests/test_dp_gpu.py covers the RCCL call path at world size 1)."""
 import json
 import os
 import subprocess
