@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Build-time guard for gemm_p4.hip.  gemm_nt_p5_kernel issues its LDS-DMA pieces as
+"""Build-time guard for gemm_p5.hip.  gemm_nt_p5_kernel issues its LDS-DMA pieces as
     s_add_u32 m0, ...; s_nop 0; global_load_lds_dwordx4 v, s[base:base+1]
 i.e. with the one wait state M0 needs and none for the SGPR base.  That is only safe while the base was not written by
 a VALU instruction (v_readlane_b32 of an SGPR spill slot, v_readfirstlane_b32) in the 5 wait states before the DMA:
 hipcc pads its own instructions for that hazard, not inline asm.  This script walks the kernel's assembly backwards
 from every piece and fails the build when such a write (or a label it cannot see across) is closer than 5 wait states.
 
-    python3 check_spills.py build/gemm_p4-hip-amdgcn-amd-amdhsa-gfx950.s
+    python3 check_spills.py build/gemm_p5-hip-amdgcn-amd-amdhsa-gfx950.s
 """
 import re
 import sys

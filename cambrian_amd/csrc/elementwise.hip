@@ -551,4 +551,4 @@ extern "C" int cmb_resample_bilinear(int dtype, const void* in, int64_t B, int32
 }
 
 extern "C" const char* cmb_version(void) { return "cambrian_amd 0.1.0 gfx950"; }
-extern "C" int cmb_abi_version(void) { return 1; }
+extern "C" int cmb_abi_version(void) { return CMB_ABI_VERSION; }

@@ -240,9 +240,8 @@ static int tile_override() {
   }
   return v;
 }
-static bool use_tile256(int M, int N, int splits, int hint) {
-  const int ov = hint ? hint : tile_override();
-  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2570 || ov == 2590 || (ov >= 2600 && ov < 7000)) return true;
+static bool use_tile256(int M, int N, int splits, int ov) {
+  if (ov == 256 || ov == 2560 || ov == 2561 || ov == 2590) return true;
   if (ov == 128) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
@@ -261,14 +260,29 @@ static bool tile_span_fits_u32(const RowMap& m, int64_t ldb) {
   return 2.0 * span + 256.0 < 4.0e9 && 2.0 * 256.0 * (double)ldb + 256.0 < 4.0e9;
 }
 
-// gemm_p4.hip walks 32-deep stages NS ahead across tile boundaries: every item (tile x K slice) must be at least NS
-// stages long.
-static bool p4_ok(const GemmParams& p, int splits, int ns) {
+// gemm_p5.hip stages two 64-deep tiles ahead across item boundaries: every item (tile x K slice) must be at least two
+// tiles long.
+static bool p5_ok(const GemmParams& p, int splits) {
   const int last = p.K - (splits - 1) * p.k_per_split;
-  return last / 32 >= ns && p.k_per_split / 32 >= ns;
+  return last >= 128 && p.k_per_split >= 128;
 }
 
 static thread_local int g_last_kernel = 0;  // cmb_gemm_last_kernel()
+
+// Per-shape dispatch policy (round 3, cmb_gemm_policy_set): which bf16 kernel a (M, N, K, act) problem takes when the
+// caller gives no tile_hint.  Filled by the host's start-up calibration (cambrian_amd/ops.py::calibrate_gemm_dispatch
+// times the candidates on THIS device — the 4-wave kernel's lead over the 8-wave one varies from box to box) and read
+// by every launch: a handful of entries, linear scan.  Written only between steps (no launches in flight on other
+// threads); the kernels it selects between are bit-identical in their results (tests/test_gemm256_gpu.py).
+struct PolicyEntry { int64_t M, N, K; int act, kernel; };
+constexpr int kMaxPolicy = 64;
+static PolicyEntry g_policy[kMaxPolicy];
+static int g_npolicy = 0;
+static int policy_lookup(int64_t M, int64_t N, int64_t K, int act) {
+  for (int i = 0; i < g_npolicy; ++i)
+    if (g_policy[i].M == M && g_policy[i].N == N && g_policy[i].K == K && g_policy[i].act == act) return g_policy[i].kernel;
+  return 0;
+}
 
 // Where the register-buffered 4-wave kernel is the default 256 x 256 kernel (measured, profiles/r02_gemm_lab.md): whole
 // tile columns (a ragged one leaves through its generic epilogue and drains the DMA pipeline: N = 1152 runs 20-40 %
@@ -283,6 +297,21 @@ static bool p5_default(const GemmParams& p, int splits) {
     min_tiles = e ? atol(e) : 257;
   }
   return p.N % 256 == 0 && !p.P && tiles >= min_tiles;
+}
+
+// Which bf16 kernel a problem takes.  tile_hint / CMB_GEMM_TILE: 0 = the per-shape policy if the host calibrated one for
+// this (M, N, K, act), else the cost model (128x128 tile, or a 256x256 tile: the 4-wave register-buffered kernel
+// gemm_nt_p5_kernel where p5_default() says, else the 8-wave kernel) | 128 | 256 (as the cost model's 256 branch) |
+// 2560 / 2561 (8-wave kernel, schedule 0 / 1) | 2590 (gemm_nt_p5_kernel).
+// Measured on the path's shapes (profiles/r02_gemm_lab.md): p5 is 3-11 % ahead of the 8-wave kernel when N is a
+// multiple of 256 and up to 40 % behind when it is not (N = 384, 1152).
+static int choose_bf16_kernel(const GemmParams& p, int splits, int hint, int* sched) {
+  int ov = hint ? hint : tile_override();
+  if (!ov && !p.slabs) ov = policy_lookup(p.M, p.N, p.K, p.act);
+  *sched = ov == 2561 ? 1 : 0;
+  if (!use_tile256(p.M, p.N, splits, ov) || !tile_span_fits_u32(p.a_map, p.ldb)) return 128;
+  if ((ov == 2590 || ((ov == 0 || ov == 256) && p5_default(p, splits))) && p5_ok(p, splits)) return 2590;
+  return 256;
 }
 
 template <typename T>
@@ -328,23 +357,12 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   }
   int rc;
   if constexpr (sizeof(T) == 2) {
-    // tile_hint / CMB_GEMM_TILE: 0 = cost model (128x128 tile, or a 256x256 tile: the 4-wave register-buffered kernel
-    // gemm_nt_p5_kernel where it applies, else the 8-wave kernel) | 128 | 256 (as the cost model's 256 branch) | 2560 /
-    // 2561 (8-wave kernel, schedule 0 / 1) | 2570 (4-wave ring kernel, gemm_nt_p4_kernel) | 2590 (gemm_nt_p5_kernel) | 2600 + bits / 2700 + bits (ablations of the ring / p5 kernels, lab builds).
-    // Measured on the path's shapes (profiles/r02_gemm_lab.md): p5 is 3-11 % ahead of the 8-wave kernel when N is a
-    // multiple of 256 and up to 40 % behind when it is not (N = 384, 1152), so the default takes it where p5_default()
-    // says; the ring kernel is behind everywhere (as was a 256x128 two-workgroups-per-CU design, removed).
-    const int ov = d->tile_hint ? d->tile_hint : tile_override();
-    const bool want_p4 = ov == 2570 || (ov >= 2600 && ov < 2700);
-    if (!use_tile256(p.M, p.N, splits, d->tile_hint) || !tile_span_fits_u32(p.a_map, p.ldb))
-      g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
-    else if ((ov == 2590 || (ov >= 2700 && ov < 7000) || ((ov == 0 || ov == 256) && p5_default(p, splits))) &&
-             p4_ok(p, splits, 4))  // two 64-deep tiles per item
-      g_last_kernel = 2590, rc = launch_gemm_p5_bf16(p, splits, ov >= 2700 ? ov - 2700 : 0, s);
-    else if (want_p4 && p4_ok(p, splits, 5))
-      g_last_kernel = 2570, rc = launch_gemm_p4_bf16(p, splits, 5, ov >= 2600 ? ov - 2600 : 0, s);
-    else
-      g_last_kernel = 256, rc = launch_gemm256_bf16(p, splits, ov == 2561 ? 1 : 0, s);
+    int sched = 0;
+    const int kern = choose_bf16_kernel(p, splits, d->tile_hint, &sched);
+    g_last_kernel = kern;
+    if (kern == 128) rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+    else if (kern == 2590) rc = launch_gemm_p5_bf16(p, splits, s);
+    else rc = launch_gemm256_bf16(p, splits, sched, s);
   } else {
     g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   }
@@ -368,7 +386,26 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
 
 extern "C" int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint) {
   if (dtype != CMB_BF16) return 128;
-  return use_tile256((int)M, (int)N, split_k > 1 ? split_k : 1, tile_hint) ? 256 : 128;
+  return use_tile256((int)M, (int)N, split_k > 1 ? split_k : 1, tile_hint ? tile_hint : tile_override()) ? 256 : 128;
+}
+
+extern "C" int cmb_gemm_policy_set(int64_t M, int64_t N, int64_t K, int32_t act, int32_t kernel) {
+  if (kernel != 0 && kernel != 128 && kernel != 2560 && kernel != 2590) return CMB_ERR_BAD_ARG;
+  for (int i = 0; i < g_npolicy; ++i)
+    if (g_policy[i].M == M && g_policy[i].N == N && g_policy[i].K == K && g_policy[i].act == act) {
+      if (kernel) { g_policy[i].kernel = kernel; return CMB_OK; }
+      g_policy[i] = g_policy[--g_npolicy];
+      return CMB_OK;
+    }
+  if (!kernel) return CMB_OK;
+  if (g_npolicy == kMaxPolicy) return CMB_ERR_WORKSPACE;
+  g_policy[g_npolicy++] = PolicyEntry{M, N, K, act, kernel};
+  return CMB_OK;
+}
+
+extern "C" int cmb_gemm_policy_clear(void) {
+  g_npolicy = 0;
+  return CMB_OK;
 }
 
 extern "C" int cmb_gemm_last_kernel(void) { return g_last_kernel; }

@@ -158,9 +158,8 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
 // sched: 0 = 8-phase ping-pong (two barriers per phase), 1 = in-wave pipeline (one barrier per K-tile).
 int launch_gemm256_bf16(GemmParams& p, int splits, int sched, hipStream_t s);
 
-// gemm_p4.hip: persistent 256x256 bf16 tile, 4 waves x (128 x 128), LDS ring of `ns` (4 or 5) 32-deep stages.
-int launch_gemm_p4_bf16(GemmParams& p, int splits, int ns, int var, hipStream_t s);
-// 4 waves, 64-deep tiles, the tile's fragments in registers, two LDS buffers (gemm_p4.hip: gemm_nt_p5_kernel)
-int launch_gemm_p5_bf16(GemmParams& p, int splits, int var, hipStream_t s);
+// gemm_p5.hip: persistent 256x256 bf16 tile, 4 waves x (128 x 128), 64-deep tiles, the tile's fragments in registers,
+// two LDS buffers (gemm_nt_p5_kernel)
+int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s);
 
 }  // namespace cmb_gemm_detail

@@ -281,40 +281,69 @@ __global__ void __launch_bounds__(256) fold_kv_fwd_kernel(const float* __restric
   if (lane == 0) b_out[row] = dot;
 }
 
-// block = 64 columns of one half (K or V) x all H rows; wave w takes rows w, w + 4, ...; the four partial column sums meet
-// in LDS (fixed order: deterministic)
+// Backward, two deterministic passes (round 3; the first version ran 32 workgroups of 4-byte accesses: 119 us for 24 MB):
+//   pass 1  grid (K / 256, H / 32, 2 halves): a workgroup owns 32 rows x 256 columns of one half, a wave 8 of those rows,
+//           a lane 4 consecutive columns (16-byte accesses); it writes dW for its block and the block's column sums of
+//           dw o W (-> dgamma) and db[r] W (-> dbeta) into part[half][slab][2][K] — the four waves' sums meet in LDS in
+//           a fixed order;
+//   pass 2  one thread per (half, which, column): the H / 32 slab partials summed in slab order.
+// No atomics: run-to-run bit-identical.  `part` is caller-owned workspace (cmb_sva_fold_kv_bwd_workspace bytes).
+constexpr int kFoldRows = 32;
+
 __global__ void __launch_bounds__(256) fold_kv_bwd_kernel(const float* __restrict__ dw_out, const float* __restrict__ db_out,
                                                           const float* __restrict__ wk, const float* __restrict__ gk,
                                                           const float* __restrict__ bk, const float* __restrict__ wv,
                                                           const float* __restrict__ gv, const float* __restrict__ bv, int H,
-                                                          int K, float* __restrict__ dwk, float* __restrict__ dgk,
-                                                          float* __restrict__ dbk, float* __restrict__ dwv,
-                                                          float* __restrict__ dgv, float* __restrict__ dbv) {
-  __shared__ float red[2][4][64];
+                                                          int K, float* __restrict__ dwk, float* __restrict__ dwv,
+                                                          float* __restrict__ part, int nslab) {
+  __shared__ float4 red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool isv = blockIdx.y != 0;
-  const int c = blockIdx.x * 64 + lane;
+  const bool isv = blockIdx.z != 0;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int slab = blockIdx.y;
   const float* w = isv ? wv : wk;
   const float* dwo = dw_out + (isv ? (int64_t)H * K : 0);
   const float* dbo = db_out + (isv ? H : 0);
   float* dw = isv ? dwv : dwk;
-  float sg = 0.f, sb = 0.f;
+  float4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
   if (c < K) {
-    const float g = (isv ? gv : gk)[c], b = (isv ? bv : bk)[c];
-    for (int r = wave; r < H; r += 4) {
-      const float x = w[(int64_t)r * K + c], d = dwo[(int64_t)r * K + c], e = dbo[r];
-      dw[(int64_t)r * K + c] = d * g + e * b;
-      sg += d * x;
-      sb += e * x;
+    const float4 g = *reinterpret_cast<const float4*>((isv ? gv : gk) + c);
+    const float4 b = *reinterpret_cast<const float4*>((isv ? bv : bk) + c);
+    const int r0 = slab * kFoldRows + wave * (kFoldRows / 4);
+#pragma unroll
+    for (int i = 0; i < kFoldRows / 4; ++i) {
+      const int r = r0 + i;
+      if (r < H) {
+        const float4 x = *reinterpret_cast<const float4*>(w + (int64_t)r * K + c);
+        const float4 d = *reinterpret_cast<const float4*>(dwo + (int64_t)r * K + c);
+        const float e = dbo[r];
+        const float4 o = {d.x * g.x + e * b.x, d.y * g.y + e * b.y, d.z * g.z + e * b.z, d.w * g.w + e * b.w};
+        *reinterpret_cast<float4*>(dw + (int64_t)r * K + c) = o;
+        sg.x += d.x * x.x; sg.y += d.y * x.y; sg.z += d.z * x.z; sg.w += d.w * x.w;
+        sb.x += e * x.x; sb.y += e * x.y; sb.z += e * x.z; sb.w += e * x.w;
+      }
     }
   }
   red[0][wave][lane] = sg;
   red[1][wave][lane] = sb;
   __syncthreads();
-  if (wave == 0 && c < K) {
-    (isv ? dgv : dgk)[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    (isv ? dbv : dbk)[c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+  if (wave < 2 && c < K) {  // wave 0: dgamma partial, wave 1: dbeta partial
+    const float4 a0 = red[wave][0][lane], a1 = red[wave][1][lane], a2 = red[wave][2][lane], a3 = red[wave][3][lane];
+    const float4 t = {((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
+                      ((a0.w + a1.w) + a2.w) + a3.w};
+    *reinterpret_cast<float4*>(part + (((int64_t)(isv ? 1 : 0) * nslab + slab) * 2 + wave) * K + c) = t;
   }
+}
+
+__global__ void __launch_bounds__(256) fold_kv_bwd_reduce_kernel(const float* __restrict__ part, int nslab, int K,
+                                                                 float* __restrict__ dgk, float* __restrict__ dbk,
+                                                                 float* __restrict__ dgv, float* __restrict__ dbv) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // (half, which, column)
+  if (idx >= 4 * K) return;
+  const int c = idx % K, which = (idx / K) & 1, half = idx / (2 * K);
+  float s = 0.f;
+  for (int sl = 0; sl < nslab; ++sl) s += part[(((int64_t)half * nslab + sl) * 2 + which) * K + c];
+  (half ? (which ? dbv : dgv) : (which ? dbk : dgk))[c] = s;
 }
 
 }  // namespace
@@ -328,14 +357,26 @@ extern "C" int cmb_sva_fold_kv_fwd(const float* wk, const float* gk, const float
   return CMB_OK;
 }
 
+extern "C" int64_t cmb_sva_fold_kv_bwd_workspace(int64_t H, int64_t K) {
+  if (H <= 0 || K <= 0) return 0;
+  return 2 * ((H + kFoldRows - 1) / kFoldRows) * 2 * K * (int64_t)sizeof(float);
+}
+
 extern "C" int cmb_sva_fold_kv_bwd(const float* dw_out, const float* db_out, const float* wk, const float* gk, const float* bk,
                                    const float* wv, const float* gv, const float* bv, int64_t H, int64_t K, float* dwk,
-                                   float* dgk, float* dbk, float* dwv, float* dgv, float* dbv, void* stream) {
+                                   float* dgk, float* dbk, float* dwv, float* dgv, float* dbv, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
   if (!dw_out || !db_out || !wk || !gk || !bk || !wv || !gv || !bv || !dwk || !dgk || !dbk || !dwv || !dgv || !dbv || H <= 0 ||
-      K <= 0)
+      K <= 0 || (K & 3))
     return CMB_ERR_BAD_ARG;
-  hipLaunchKernelGGL(fold_kv_bwd_kernel, dim3((unsigned)((K + 63) / 64), 2), dim3(256), 0, (hipStream_t)stream, dw_out, db_out, wk,
-                     gk, bk, wv, gv, bv, (int)H, (int)K, dwk, dgk, dbk, dwv, dgv, dbv);
+  if (!workspace || workspace_bytes < cmb_sva_fold_kv_bwd_workspace(H, K)) return CMB_ERR_WORKSPACE;
+  const int nslab = (int)((H + kFoldRows - 1) / kFoldRows);
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(fold_kv_bwd_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)nslab, 2), dim3(256), 0, (hipStream_t)stream,
+                     dw_out, db_out, wk, gk, bk, wv, gv, bv, (int)H, (int)K, dwk, dwv, part, nslab);
+  CMB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fold_kv_bwd_reduce_kernel, dim3((unsigned)((4 * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     nslab, (int)K, dgk, dbk, dgv, dbv);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

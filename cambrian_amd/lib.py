@@ -24,6 +24,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
+ABI_VERSION = 3   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
           -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
@@ -90,6 +91,8 @@ SIGNATURES = {
     "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
     "cmb_gemm_tile": (C.c_int, [C.c_int, _i64, _i64, _i32, _i32]),
     "cmb_gemm_last_kernel": (C.c_int, []),
+    "cmb_gemm_policy_set": (C.c_int, [_i64, _i64, _i64, _i32, _i32]),
+    "cmb_gemm_policy_clear": (C.c_int, []),
     "cmb_quantize_fp8_rows": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
@@ -108,7 +111,8 @@ SIGNATURES = {
     "cmb_embed_splice_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p]),
     "cmb_embed_splice_bwd": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _i64, _i32, _p, _p, _p]),
     "cmb_sva_fold_kv_fwd": (C.c_int, [_p] * 6 + [_i64, _i64, _p, _p, _p]),
-    "cmb_sva_fold_kv_bwd": (C.c_int, [_p] * 8 + [_i64, _i64] + [_p] * 7),
+    "cmb_sva_fold_kv_bwd": (C.c_int, [_p] * 8 + [_i64, _i64] + [_p] * 7 + [_i64, _p]),
+    "cmb_sva_fold_kv_bwd_workspace": (_i64, [_i64, _i64]),
     "cmb_token_mean_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_token_mean_bwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_vit_attn_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i32, _i32, _f, _p, _i32, _p]),
@@ -149,6 +153,11 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = lib.cmb_abi_version()
+        if got != ABI_VERSION:
+            raise CambrianAmdError(
+                f"{LIB_PATH} reports ABI revision {got}, this binding is written against {ABI_VERSION}: every symbol of a "
+                "stale build still resolves but argument lists have shifted — rebuild it (`make -C cambrian_amd/csrc`)")
         _lib = lib
     return _lib
 

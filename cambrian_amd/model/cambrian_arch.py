@@ -5,7 +5,8 @@ Same mixins, method names, argument lists, 10-tuple return and state-dict keys a
 ``rearrange_vision_tower_features_train:271``, ``encode_images:332``, ``prepare_inputs_labels_for_multimodal:340``).
 The static ("XLA"/training) branch — the hot path of the north star — is implemented; it is selected by
 ``cambrian_amd.model.STATIC_PATH`` instead of ``torch_xla`` being importable (SURVEY.md §8b "path switch").
-The dynamic eval/generate branch (:388-390,422-451,492-609) is the next row and raises.
+The dynamic eval/generate branch (:203-256,289-330,388-390,422-451,492-609) is ``_prepare_inputs_dynamic``
+below (variable query counts per image, per-sample masks; ``rearrange_vision_tower_features_inference``, ``unpad_image``).
 
 MI355X-first differences inside the same contract:
   * aux features stay in tower-token-major layout; the window partition of :271-287 is folded into the SVA
@@ -291,6 +292,7 @@ class CambrianMetaForCausalLM(ABC):
         dtype = image_aux_list[0].dtype
         image_token_len = cfg.image_token_len
         side = int(image_token_len ** 0.5)
+        span = ops.region_begin("towers_connector")                                 # (bench.py roofline.region)
         feats_raw = self.encode_images(image_aux_list)                              # :366
 
         sva_ctx = None
@@ -331,6 +333,8 @@ class CambrianMetaForCausalLM(ABC):
         # newline column + splice into the token embeddings: one gather kernel (:413-420, :457-490)
         inputs_embeds, _pos = ops.embed_splice(input_ids, model.embed_tokens.weight, image_features.view(bs, side * side, H),
                                                model.image_newline, side, IMAGE_TOKEN_INDEX)
+        inputs_embeds = ops.region_mark(inputs_embeds, span, "b0")  # its backward runs to the end of backward(): region_close
+        ops.region_fwd_end(span)
         final_size = [(side, side)] * bs
         if sva_ctx is None:
             return None, position_ids, attention_mask, past_key_values, inputs_embeds, labels, None, None, final_size, None

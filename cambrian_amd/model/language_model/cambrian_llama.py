@@ -357,11 +357,17 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
         p0 = cfg.image_position
         side = int(cfg.image_token_len ** 0.5)
         hidden = hidden if hidden.is_contiguous() else hidden.contiguous()
-        q2 = ops.gather_query_rows(hidden, p0, side)                                   # [B*576, H]
+        span = ops.region_begin("sva_in_llm")                                          # (bench.py roofline.region)
+        link = {}                                                                      # gather / scatter share d(hidden)
+        q2 = ops.gather_query_rows(hidden, p0, side, link)                             # [B*576, H]
+        q2 = ops.region_mark(q2, span, "b1")
         feats = [f if f.dtype == q2.dtype else f.to(q2.dtype) for f in sva.feats]      # :186
         out = self.vision_sampler_layers[k].forward_fused(q2, sva.ctx_b.to(q2.dtype), feats, sva.masks_u8, sva.holders,
                                                          sva.B, side)
-        return ops.scatter_query_rows(hidden, out, p0, side)
+        out = ops.region_mark(out, span, "b0")
+        hidden = ops.scatter_query_rows(hidden, out, p0, side, link)
+        ops.region_fwd_end(span)
+        return hidden
 
 
 class _BackboneShim:

@@ -114,6 +114,9 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     else:
         d.workspace, d.workspace_bytes = None, 0
+    if GEMM_CENSUS is not None and dt == torch.bfloat16 and split_k <= 1 and tile == 0:
+        key = (M, N, K, act, pre_out is not None)
+        GEMM_CENSUS[key] = GEMM_CENSUS.get(key, 0) + 1
     prof = GEMM_PROFILE
     tile_used = 0
     if prof is not None:  # HIP events on the launch stream around this launch (bench.py roofline leg)
@@ -238,6 +241,137 @@ def fp8_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
 # bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k, tile, shape, kernel id) per GEMM launch
 GEMM_PROFILE = None
 GEMM_PROFILE_TILE = 0  # 0 = time every GEMM launch; 128 / 256 = only launches of that tile configuration
+# {(M, N, K, act, has_pre_out): launches} of the bf16 launches that left the kernel choice to the library, while set to a dict
+GEMM_CENSUS = None
+
+
+class gemm_census:
+    """``with ops.gemm_census() as c: step()`` — counts the bf16 GEMM problems of one step (no events, no syncs); the
+    input of ``calibrate_gemm_dispatch``."""
+
+    def __enter__(self):
+        global GEMM_CENSUS
+        self.prev, GEMM_CENSUS = GEMM_CENSUS, {}
+        self.shapes = GEMM_CENSUS
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_CENSUS
+        GEMM_CENSUS = self.prev
+        return False
+
+    def top(self, n: int = 8):
+        """The n problems with the most FLOPs per step among those where both 256 x 256 kernels apply: whole tile
+        columns, K of at least two 64-deep tiles, no pre-activation copy, more than one round of tiles."""
+        rows = []
+        for (M, N, K, act, pre), cnt in self.shapes.items():
+            tiles = ((M + 255) // 256) * (N // 256)
+            if pre or N % 256 or K < 128 or K % 64 or tiles <= 256:
+                continue
+            rows.append((2.0 * M * N * K * cnt, (M, N, K, act)))
+        rows.sort(reverse=True)
+        return [r[1] for r in rows[:n]]
+
+
+def calibrate_gemm_dispatch(shapes, iters: int = 3, device=None, candidates=(2590, 2560)):
+    """Start-up calibration of the 256 x 256 kernel choice on THIS device (VERDICT r2 #1d): every (M, N, K, act) in
+    ``shapes`` is run ``iters`` times (after one untimed launch) with each candidate kernel — interleaved, random bf16
+    operands, HIP events on the current stream — and the fastest is registered in the library's per-shape policy
+    (``cmb_gemm_policy_set``), which every later ``cmb_gemm`` of that problem without a ``tile_hint`` follows.  The
+    candidates (2590 = 4-wave register-buffered kernel, 2560 = 8-wave kernel) give bit-identical results, so this
+    changes speed only.  Returns one dict per shape (microseconds per candidate, the choice).  ~1-2 ms per shape."""
+    lib = L.load()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    report = []
+    for (M, N, K, act) in shapes:
+        a = torch.randn((M, K), device=device, dtype=torch.bfloat16)
+        w = torch.randn((N, K), device=device, dtype=torch.bfloat16)
+        out = torch.empty((M, N), device=device, dtype=torch.bfloat16)
+        evs = {c: [] for c in candidates}
+        for it in range(iters + 1):
+            for c in candidates:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                k_gemm(a, w, act=act, out=out, tile=c)
+                e1.record()
+                if it:
+                    evs[c].append((e0, e1))
+        torch.cuda.synchronize(device)
+        us = {c: min(e0.elapsed_time(e1) for e0, e1 in evs[c]) * 1e3 for c in candidates}
+        best = min(us, key=us.get)
+        L.check(lib.cmb_gemm_policy_set(M, N, K, act, best), "cmb_gemm_policy_set")
+        report.append({"M": M, "N": N, "K": K, "act": act, "us": {str(c): round(v, 1) for c, v in us.items()},
+                       "choice": best, "TFLOPs": {str(c): round(2.0 * M * N * K / v / 1e6, 1) for c, v in us.items()}})
+        del a, w, out
+    return report
+
+
+# ---- region timing (bench.py ``roofline.region``: the tower + SVA part of the step, forward and backward) -----------
+# While REGION_PROFILE is a list, the model glue brackets each piece of the region with HIP events on the launch
+# stream: ``region_begin`` / ``region_fwd_end`` in the forward, and identity autograd nodes (``region_mark``) whose
+# backward records the events of the matching backward span — the node on the piece's OUTPUT fires when its backward
+# starts ("b0"), the node on its INPUT when the gradient leaves the piece ("b1": autograd runs the nodes of the piece,
+# created after the input mark, before it).  Spans without an input mark (the first piece: towers have no input
+# gradient) are closed by ``region_close`` after ``backward()`` returned.
+REGION_PROFILE = None
+
+
+def _event():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+class _RegionMarkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, span, key):
+        ctx.span, ctx.key = span, key
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.key not in ctx.span:
+            ctx.span[ctx.key] = _event()
+        return g, None, None
+
+
+def region_begin(tag: str):
+    """Forward start of a span (None when nobody profiles)."""
+    if REGION_PROFILE is None:
+        return None
+    span = {"tag": tag, "f0": _event()}
+    REGION_PROFILE.append(span)
+    return span
+
+
+def region_mark(x: torch.Tensor, span, key: str) -> torch.Tensor:
+    """key "b1" on a piece's input, "b0" on its output (see above)."""
+    if span is None or not x.requires_grad:
+        return x
+    return _RegionMarkFn.apply(x, span, key)
+
+
+def region_fwd_end(span) -> None:
+    if span is not None:
+        span["f1"] = _event()
+
+
+def region_close() -> None:
+    """After backward(): spans whose backward started ("b0") but has no input mark end here."""
+    if REGION_PROFILE is None:
+        return
+    e = None
+    for span in REGION_PROFILE:
+        if "b0" in span and "b1" not in span:
+            e = e or _event()
+            span["b1"] = e
+
+
+def region_ms(spans) -> dict:
+    """Forward / backward milliseconds of the recorded spans (call after a device synchronise)."""
+    fwd = sum(s["f0"].elapsed_time(s["f1"]) for s in spans if "f1" in s)
+    bwd = sum(s["b0"].elapsed_time(s["b1"]) for s in spans if "b0" in s and "b1" in s)
+    return {"fwd_ms": fwd, "bwd_ms": bwd, "spans": len(spans)}
 
 
 def k_transpose(x: torch.Tensor, r_pad: Optional[int] = None) -> torch.Tensor:
@@ -596,7 +730,7 @@ class FoldKVFn(torch.autograd.Function):
         for t in ts:
             L.require_gpu(t)
             if t.dtype != torch.float32:
-                raise L.CambrianAmdError("fold_kv: fp32 master parameters expected")
+                raise L.CambrianAmdError("fold_kv: fp32 tensors expected (ops.fold_kv up-casts other parameter dtypes)")
         H, K = ts[0].shape
         w = torch.empty((2 * H, K), dtype=torch.float32, device=ts[0].device)
         b = torch.empty((2 * H,), dtype=torch.float32, device=ts[0].device)
@@ -613,14 +747,18 @@ class FoldKVFn(torch.autograd.Function):
         dw = torch.zeros((2 * H, K), dtype=torch.float32, device=dev) if dw is None else dw.contiguous().float()
         db = torch.zeros((2 * H,), dtype=torch.float32, device=dev) if db is None else db.contiguous().float()
         outs = [torch.empty_like(t) for t in ts]
+        ws = torch.empty((L.load().cmb_sva_fold_kv_bwd_workspace(H, K) // 4,), dtype=torch.float32, device=dev)
         rc = L.load().cmb_sva_fold_kv_bwd(dw.data_ptr(), db.data_ptr(), *[t.data_ptr() for t in ts], H, K,
-                                          *[o.data_ptr() for o in outs], L.stream_ptr(dev))
+                                          *[o.data_ptr() for o in outs], ws.data_ptr(), ws.numel() * 4, L.stream_ptr(dev))
         L.check(rc, "cmb_sva_fold_kv_bwd")
         return tuple(outs)
 
 
 def fold_kv(wk, gk, bk, wv, gv, bv):
-    return FoldKVFn.apply(wk, gk, bk, wv, gv, bv)
+    """Folded K|V weight / bias in fp32.  Parameters that are not fp32 masters (a module moved with ``.to(bfloat16)`` /
+    ``.half()``) are up-cast by autograd-tracked ``.float()`` first, as the torch expression this replaces did."""
+    ts = [t if t.dtype == torch.float32 else t.float() for t in (wk, gk, bk, wv, gv, bv)]
+    return FoldKVFn.apply(*ts)
 
 
 # ================================================================================================
@@ -833,38 +971,51 @@ def hook_row_map(S: int, H: int, side: int) -> RowMap:
 
 class GatherQueryRowsFn(torch.autograd.Function):
     """hidden [B,S,H] -> the side*side latent-query rows [B*side*side, H] starting at ``pos`` (newline column
-    skipped): ``hidden[:, pos:pos+side*(side+1)].view(B,side,side+1,H)[:, :, :side]`` as one strided copy."""
+    skipped): ``hidden[:, pos:pos+side*(side+1)].view(B,side,side+1,H)[:, :, :side]`` as one strided copy.
+
+    ``link`` (a dict shared with the ScatterQueryRowsFn of the same hook, or None): the hook reads these rows of
+    ``hidden`` and then overwrites exactly them, so d(hidden) = [text / newline rows: the scatter's incoming gradient;
+    query rows: this gather's].  Returned as two dense tensors autograd would zero-fill one, clone the other and add
+    them (4 extra passes over [B,S,H] per hook).  With a link the scatter's backward — autograd runs it first — leaves
+    its result in ``link["dh"]`` and this backward writes its rows into that buffer and returns None (a consumer that
+    returns no gradient adds nothing; the decoder layer's backward runs only after both nodes)."""
 
     @staticmethod
-    def forward(ctx, hidden, pos: int, side: int):
+    def forward(ctx, hidden, pos: int, side: int, link=None):
         B, S, H = hidden.shape
         assert hidden.is_contiguous()
         out = torch.empty((B * side * side, H), dtype=hidden.dtype, device=hidden.device)
         k_copy_rows(hidden.view(-1)[pos * H:], hook_row_map(S, H, side), out, L.identity_map(H), B * side * side, H)
         ctx.cfg = (B, S, H, pos, side)
+        ctx.link = link
         return out
 
     @staticmethod
     def backward(ctx, g):
         B, S, H, pos, side = ctx.cfg
         g = g.contiguous()
+        dh = ctx.link.pop("dh", None) if ctx.link is not None else None
+        if dh is not None and dh.dtype == g.dtype:
+            k_copy_rows(g, L.identity_map(H), dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)
+            return None, None, None, None
         dh = torch.zeros((B, S, H), dtype=g.dtype, device=g.device)
         k_copy_rows(g, L.identity_map(H), dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)
-        return dh, None, None
+        return dh, None, None, None
 
 
 class ScatterQueryRowsFn(torch.autograd.Function):
     """In-place write-back of the updated latent queries into ``hidden`` (the reference's
     ``hidden_states[:, a:b] = latent_query_with_newline``, cambrian_llama.py:207); the newline column and all
-    text rows are untouched."""
+    text rows are untouched.  ``link``: see GatherQueryRowsFn."""
 
     @staticmethod
-    def forward(ctx, hidden, rows, pos: int, side: int):
+    def forward(ctx, hidden, rows, pos: int, side: int, link=None):
         B, S, H = hidden.shape
         assert hidden.is_contiguous() and rows.is_contiguous()
         k_copy_rows(rows, L.identity_map(H), hidden.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)
         ctx.mark_dirty(hidden)
         ctx.cfg = (B, S, H, pos, side)
+        ctx.link = link
         return hidden
 
     @staticmethod
@@ -875,15 +1026,17 @@ class ScatterQueryRowsFn(torch.autograd.Function):
         k_copy_rows(g.view(-1)[pos * H:], hook_row_map(S, H, side), drows, L.identity_map(H), B * side * side, H)
         dh = g.clone()
         k_copy_rows(None, None, dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)  # zero the rows
-        return dh, drows, None, None
+        if ctx.link is not None and ctx.needs_input_grad[0]:
+            ctx.link["dh"] = dh
+        return dh, drows, None, None, None
 
 
-def gather_query_rows(hidden, pos: int, side: int):
-    return GatherQueryRowsFn.apply(hidden, pos, side)
+def gather_query_rows(hidden, pos: int, side: int, link=None):
+    return GatherQueryRowsFn.apply(hidden, pos, side, link)
 
 
-def scatter_query_rows(hidden, rows, pos: int, side: int):
-    return ScatterQueryRowsFn.apply(hidden, rows, pos, side)
+def scatter_query_rows(hidden, rows, pos: int, side: int, link=None):
+    return ScatterQueryRowsFn.apply(hidden, rows, pos, side, link)
 
 
 # ================================================================================================

@@ -142,9 +142,20 @@ class Zero2AdamW:
             w.wait()
 
     def zero_grad(self, set_to_none: bool = True) -> None:
+        """Drops this step's gradients INCLUDING what the hooks already accumulated / launched: after a skipped step
+        (non-finite loss followed by ``zero_grad()``, an exception between backward and step) the next backward starts
+        from zero instead of adding to stale sums or tripping the "gradient after the reduce-scatter" check."""
         for b in self.buckets:
+            if b.work is not None:       # a launched reduce-scatter must finish before its buffers are reused
+                b.work.wait()
+                b.work = None
+            if b.pending != len(b.params) or self.world == 1:
+                b.flat_grad.zero_()
+            b.pending = len(b.params)
             for p in b.params:
                 p.grad = None
+        for s_ in self._shards:
+            s_.grad = None
 
     def state_bytes(self) -> int:
         """optimizer-state bytes held by THIS rank (2 fp32 moments per owned element)."""

@@ -5,15 +5,23 @@ scripts/zero3.json).
 One ``Zero3Unit`` per wrapped module (a decoder layer).  Each rank owns 1/world of the unit's flat parameter vector;
 the full vector lives in ONE persistent flat tensor whose *storage* is sized only while the unit computes:
     forward:   pre-hook  all_gather(shards) -> full   ...   post-hook  storage.resize_(0)
-    backward:  pre-hook  all_gather again             ...   when every trainable parameter of the unit has its gradient
-               (post-accumulate hooks; frozen units: the module's backward hook): gradients are flattened,
-               reduce_scatter(SUM)/world leaves the owned shard's gradient on ``unit.shard.grad``, storage.resize_(0).
+    backward:  the unit's output gradient arrives: all_gather again   ...   when every trainable parameter of the unit
+               has its gradient (post-accumulate hooks): gradients are flattened, reduce_scatter(SUM)/world leaves the
+               owned shard's gradient on ``unit.shard.grad``, storage.resize_(0).
 The module's parameters are views of that flat tensor throughout (autograd's saved weights included), which is what lets
 the storage be dropped and refilled under them — the FSDP trick.  The optimizer steps on ``unit.shard`` only
 (``zero3_parameters``), so parameter, gradient and Adam-state memory all scale 1/world; a frozen unit (the LLM in the
 pre-training stage, train_fsdp.py:1677-1685) is sharded for memory and never produces a gradient.
 Collectives are per unit (one decoder layer of Yi-34B = 0.55 B parameters = 1.1 GB bf16: few, large messages for the
-point-to-point xGMI links).  CPU coverage: tests/test_zero3.py, gloo world 2.
+point-to-point xGMI links).
+
+Prefetch (round 3): the units of one ``zero3_wrap`` call form a chain in call order.  While unit i computes, the
+all-gather of the unit that runs next (i + 1 in the forward, i - 1 in the backward) is already in flight as an
+asynchronous collective (RCCL's own stream on the GPU; ``Work.wait()`` makes the compute stream wait for it, not the
+host), so the exchange of a layer hides behind the compute of its neighbour — the 34 B configuration moves 2 x 68 GB of
+parameters per step and is exchange-bound without it.  At most three units are resident at a time
+(previous being released, current, next landing).  ``prefetch=False`` gives the gather-right-before-use behaviour.
+CPU coverage: tests/test_zero3.py, gloo world 2 (results with and without prefetch, and the order of the collectives).
 """
 from __future__ import annotations
 
@@ -55,53 +63,115 @@ class Zero3Unit:
             off += p.numel()
         lo = self.rank * self.shard_len
         self.trainable = any(p.requires_grad for p in self.params)
+        self.n_trainable = sum(1 for p in self.params if p.requires_grad)
         self.shard = nn.Parameter(self.full[lo:lo + self.shard_len].clone(), requires_grad=self.trainable)
         self._nbytes = self.full.untyped_storage().nbytes()
         self._resident = True
-        self._pending = 0
+        self._work = None          # in-flight asynchronous all-gather into self.full (prefetch)
+        self._pending = 0          # trainable parameters whose gradient of this backward has not arrived yet
+        self._in_backward = False  # this step's backward of the unit has started (set once per backward)
+        # chain of units in call order (zero3_wrap fills these; a lone unit has no neighbours)
+        self.chain: List["Zero3Unit"] = [self]
+        self.index = 0
+        self.prefetch = False
+        self.log: Optional[list] = None   # tests: ("gather" | "prefetch" | "wait" | "release", unit index)
         self.release()
-        module.register_forward_pre_hook(lambda m, a: self.gather())
+        module.register_forward_pre_hook(self._pre_forward)
         module.register_forward_hook(self._post_forward)
         if self.trainable:
             for p in self.params:
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(self._on_grad)
 
-    # A plain tensor hook on the unit's output marks the start of its backward.  (Module backward hooks would wrap the
+    def _note(self, what: str) -> None:
+        if self.log is not None:
+            self.log.append((what, self.index))
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def _pre_forward(self, module, args) -> None:
+        self._in_backward = False      # a new forward: the next output gradient starts a new backward of this unit
+        self.gather()
+        self._start_neighbour(+1)
+
+    # Plain tensor hooks on the unit's outputs mark the start of its backward.  (Module backward hooks would wrap the
     # output in a custom-Function view, which the in-LLM SVA hook — an in-place scatter into the layer's output,
-    # cambrian_llama.py:181-207 — is not allowed to modify.)  A frozen unit has no gradient hook to release it: it is
+    # cambrian_llama.py:181-207 — is not allowed to modify.)  EVERY output tensor that requires grad carries the hook
+    # and the hook is idempotent per backward: whichever output's gradient arrives first gathers the unit (a
+    # hook on the first output only is skipped when the gradient reaches the unit through another output, and its
+    # parameter gradients would then be dropped silently).  A frozen unit has no gradient hook to release it: it is
     # dropped when the next unit's backward starts, the last one by finalize().
     _bw_prev: Optional["Zero3Unit"] = None
 
+    @staticmethod
+    def _tensors(out) -> List[torch.Tensor]:
+        if torch.is_tensor(out):
+            return [out]
+        if isinstance(out, dict):
+            out = list(out.values())
+        if isinstance(out, (tuple, list)):
+            return [o for o in out if torch.is_tensor(o)]
+        return []
+
     def _post_forward(self, module, args, out):
         self.release()
-        t = out if torch.is_tensor(out) else next((o for o in out if torch.is_tensor(o)), None)
-        if t is not None and t.requires_grad:
-            t.register_hook(self._grad_of_output)
+        for t in self._tensors(out):
+            if t.requires_grad:
+                t.register_hook(self._grad_of_output)
 
     def _grad_of_output(self, grad):
-        prev = Zero3Unit._bw_prev
-        if prev is not None and prev is not self and not prev.trainable and prev.resident:
-            prev.release()
-        Zero3Unit._bw_prev = self
-        self._pre_backward()
+        if not self._in_backward:
+            self._in_backward = True
+            prev = Zero3Unit._bw_prev
+            if prev is not None and prev is not self and not prev.trainable and prev.resident:
+                prev.release()
+            Zero3Unit._bw_prev = self
+            self._pre_backward()
         return grad
 
     # ---- residency -----------------------------------------------------------------------------------------------
-    def gather(self) -> None:
-        if self._resident:
-            return
+    def _issue(self, async_op: bool) -> None:
         self.full.untyped_storage().resize_(self._nbytes)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.full, self.shard.data, group=self.group)
+            w = dist.all_gather_into_tensor(self.full, self.shard.data, group=self.group, async_op=async_op)
+            self._work = w if async_op else None
         else:
             self.full[: self.shard_len].copy_(self.shard.data)
         self._resident = True
 
+    def gather(self) -> None:
+        """Full parameters usable by the compute stream when this returns."""
+        if self._work is not None:            # prefetched: the compute stream (host, for gloo) waits for the collective
+            self._work.wait()
+            self._work = None
+            self._note("wait")
+            return
+        if self._resident:
+            return
+        self._note("gather")
+        self._issue(async_op=False)
+
+    def start_gather(self) -> None:
+        """Begin the all-gather without waiting for it (the neighbour's prefetch)."""
+        if self._resident or self._work is not None:
+            return
+        self._note("prefetch")
+        self._issue(async_op=True)
+
+    def _start_neighbour(self, step: int) -> None:
+        if not self.prefetch:
+            return
+        j = self.index + step
+        if 0 <= j < len(self.chain):
+            self.chain[j].start_gather()
+
     def release(self) -> None:
+        if self._work is not None:            # never free storage a collective is still writing
+            self._work.wait()
+            self._work = None
         if self._resident:
             self.full.untyped_storage().resize_(0)
             self._resident = False
+            self._note("release")
 
     @property
     def resident(self) -> bool:
@@ -110,9 +180,15 @@ class Zero3Unit:
     # ---- backward ------------------------------------------------------------------------------------------------
     def _pre_backward(self) -> None:
         self.gather()
-        self._pending = sum(1 for p in self.params if p.requires_grad)
+        self._pending = self.n_trainable
+        self._start_neighbour(-1)
 
     def _on_grad(self, p: nn.Parameter) -> None:
+        if not self._in_backward or not self._resident:
+            raise RuntimeError(
+                "Zero3Unit: a parameter gradient arrived for a unit whose backward never started (none of the module's "
+                "output tensors carried the gather hook — outputs must be tensors or (nested one level) tuples / lists / "
+                "dicts of tensors), so its full parameters were not resident")
         self._pending -= 1
         if self._pending == 0:
             self._reduce_grads()
@@ -133,16 +209,21 @@ class Zero3Unit:
             g = flat[: self.shard_len].clone()
         self.shard.grad = g if self.shard.grad is None else self.shard.grad + g
         self.release()
+        self._pending = 0
 
     def finalize(self) -> None:
         """After backward(), before optimizer.step(): a trainable unit some of whose parameters received no gradient in
         this step (unused branch) never counts down to zero in ``_on_grad`` — reduce what arrived (missing gradients
-        enter the collective as zeros, every rank calls this, so the collectives stay matched) and drop the storage."""
-        if self.trainable and self._pending > 0:
+        enter the collective as zeros, every rank calls this, so the collectives stay matched) and drop the storage.
+        Also flushes a unit that still holds parameter gradients for any other reason, and cancels a prefetch that was
+        never consumed."""
+        if self.trainable and self._in_backward and (self._pending != 0 or any(p.grad is not None for p in self.params)):
             self._pending = 0
             self._reduce_grads()
-        elif self._resident:
+        else:
             self.release()
+        self._pending = 0
+        self._in_backward = False
         if Zero3Unit._bw_prev is self:
             Zero3Unit._bw_prev = None
 
@@ -154,8 +235,14 @@ class Zero3Unit:
         return out
 
 
-def zero3_wrap(modules: Iterable[nn.Module], process_group: Optional[dist.ProcessGroup] = None) -> List[Zero3Unit]:
-    return [Zero3Unit(m, process_group) for m in modules]
+def zero3_wrap(modules: Iterable[nn.Module], process_group: Optional[dist.ProcessGroup] = None,
+               prefetch: bool = True) -> List[Zero3Unit]:
+    """One unit per module, chained in the given (= call) order; ``prefetch`` starts each unit's all-gather while its
+    predecessor (forward) / successor (backward) computes."""
+    units = [Zero3Unit(m, process_group) for m in modules]
+    for i, u in enumerate(units):
+        u.chain, u.index, u.prefetch = units, i, bool(prefetch)
+    return units
 
 
 def zero3_finalize(units: Iterable[Zero3Unit]) -> None:

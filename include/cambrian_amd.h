@@ -56,7 +56,11 @@ typedef struct cmb_rowmap {
 
 /* library / build identification ("cambrian_amd <version> gfx950"). */
 const char* cmb_version(void);
-/* number of tensor-core tile configurations compiled in (diagnostic). */
+/* ABI revision: bumped whenever an entry point's signature or a descriptor's layout changes (round 2's key_valid
+ * arguments = 2, round 3's fold_kv workspace = 3).  Bindings must compare it with the revision they
+ * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
+ * library still resolves, and a shifted argument list corrupts memory instead of failing. */
+#define CMB_ABI_VERSION 3
 int cmb_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -94,7 +98,7 @@ typedef struct cmb_gemm_desc {
   int32_t tile_hint;       /* 0 = choose by grid-fill cost model; 128 / 256 = force that block tile (bf16 only);
                               2560 / 2561 = 256 tile with schedule 0 (8-phase ping-pong, default) / 1 (in-wave pipeline);
                               2590 = 4-wave register-buffered 256x256 kernel (what 0 / 256 pick when N % 256 == 0 and there is
-                              more than one round of tiles), 2570 = its ring-of-stages predecessor (gemm_p4.hip; same results) */
+                              more than one round of tiles).  0 also consults the per-shape policy (cmb_gemm_policy_set) */
   const float* a_scale;    /* CMB_FP8_E4M3 only: [M] fp32 dequantisation factor of each A row (or NULL = 1) */
   const float* b_scale;    /* CMB_FP8_E4M3 only: [N] fp32 dequantisation factor of each B row (or NULL = 1);
                               the accumulator is multiplied by a_scale[m] * b_scale[n] before alpha / bias */
@@ -111,9 +115,16 @@ int cmb_quantize_fp8_rows(int dtype, const void* x, int64_t ldx, int64_t rows, i
  * kernel configuration.  dtype CMB_F32 always answers 128. */
 int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint);
 /* which kernel the calling thread's most recent cmb_gemm launched (0 before the first): 128 = 128x128 tile kernel,
- * 256 = 8-wave 256x256 kernel (gemm256.hip), 2590 = 4-wave register-buffered 256x256 kernel (gemm_nt_p5_kernel),
- * 2570 = the opt-in persistent ring kernel.  For labelling profiles and rooflines per kernel. */
+ * 256 = 8-wave 256x256 kernel (gemm256.hip), 2590 = 4-wave register-buffered 256x256 kernel (gemm_nt_p5_kernel,
+ * gemm_p5.hip).  For labelling profiles and rooflines per kernel. */
 int cmb_gemm_last_kernel(void);
+/* Per-shape dispatch policy: bf16 launches of exactly (M, N, K, act) without a tile_hint and without split-K take
+ * `kernel` (128 | 2560 = 8-wave 256x256 | 2590 = 4-wave 256x256; 0 removes the entry) instead of the built-in cost
+ * model.  Meant for a start-up calibration on the device at hand (the candidates give bit-identical results; which is
+ * faster for a shape varies from box to box — VERDICT r2 #4).  At most 64 entries (CMB_ERR_WORKSPACE beyond); not
+ * thread-safe against concurrent cmb_gemm calls: set it between steps. */
+int cmb_gemm_policy_set(int64_t M, int64_t N, int64_t K, int32_t act, int32_t kernel);
+int cmb_gemm_policy_clear(void);
 
 /* out[C, R_pad] = in[R, C]^T, zero-filling columns R..R_pad-1 (R_pad >= R). Used to put the
  * reduction dimension innermost for weight-gradient GEMMs (autograd of the linears above). */
@@ -233,12 +244,15 @@ int cmb_embed_splice_bwd(int dtype, const void* dout, const int32_t* pos, int64_
  * Linear; the two LayerNorms share their statistics, so their affines are folded into one projection):
  *   w_out[n,:] = W[n,:] * gamma,  b_out[n] = W[n,:] . beta;  rows 0..H-1 from (wk, gk, bk), rows H..2H-1 from (wv, gv, bv).
  * All fp32 (master parameters); wk / wv [H, K] row-major, K % 4 == 0.  bwd: given d(w_out) [2H, K] and d(b_out) [2H]
- * writes dW = dw * gamma + db (x) beta, dgamma = colsum(dw o W), dbeta = W^T db for both halves.  Deterministic. */
+ * writes dW = dw * gamma + db (x) beta, dgamma = colsum(dw o W), dbeta = W^T db for both halves.  Deterministic (two
+ * passes through a caller-owned workspace of cmb_sva_fold_kv_bwd_workspace(H, K) bytes; CMB_ERR_WORKSPACE if smaller). */
 int cmb_sva_fold_kv_fwd(const float* wk, const float* gk, const float* bk, const float* wv, const float* gv, const float* bv,
                         int64_t H, int64_t K, float* w_out, float* b_out, void* stream);
 int cmb_sva_fold_kv_bwd(const float* dw_out, const float* db_out, const float* wk, const float* gk, const float* bk,
                         const float* wv, const float* gv, const float* bv, int64_t H, int64_t K, float* dwk, float* dgk,
-                        float* dbk, float* dwv, float* dgv, float* dbv, void* stream);
+                        float* dbk, float* dwv, float* dgv, float* dbv, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+int64_t cmb_sva_fold_kv_bwd_workspace(int64_t H, int64_t K);
 
 /* mean over tokens: out[b,:] = mean_t x[b,t,:]  (cambrian_arch.py:377); bwd broadcasts. */
 int cmb_token_mean_fwd(int dtype, const void* x, int64_t B, int64_t T, int64_t D, void* out,

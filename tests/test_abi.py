@@ -78,3 +78,15 @@ def test_state_dict_keys_match_reference_contract():
     assert sd["layers.0.proj_in.weight"].shape == (1024, 4096 + 1024)
     assert sd["layers.0.proj_out.linear_2.weight"].shape == (4096, 1024)
     assert sd["layers.0.pos_embed_3"].shape == (16, 1024)
+
+
+def test_abi_revision_is_checked(built, monkeypatch):
+    """a library of another ABI revision resolves every symbol and then receives shifted argument lists; the
+    binding compares cmb_abi_version() with the header revision it was written against."""
+    text = open(os.path.join(ROOT, "include", "cambrian_amd.h")).read()
+    rev = int(re.search(r"#define\s+CMB_ABI_VERSION\s+(\d+)", text).group(1))
+    assert built.ABI_VERSION == rev == built.load().cmb_abi_version()
+    monkeypatch.setattr(built, "_lib", None)
+    monkeypatch.setattr(built, "ABI_VERSION", rev + 1)
+    with pytest.raises(built.CambrianAmdError, match="ABI revision"):
+        built.load()

@@ -45,6 +45,6 @@ def test_label_in_front_of_a_piece_is_flagged(tmp_path):
 
 
 def test_real_build_passes_if_present():
-    s = os.path.join(ROOT, "cambrian_amd", "csrc", "build", "gemm_p4-hip-amdgcn-amd-amdhsa-gfx950.s")
+    s = os.path.join(ROOT, "cambrian_amd", "csrc", "build", "gemm_p5-hip-amdgcn-amd-amdhsa-gfx950.s")
     if os.path.exists(s):
         assert cs.main(s) == 0

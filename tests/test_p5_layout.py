@@ -1,4 +1,4 @@
-"""CPU check of the address arithmetic `gemm_nt_p5_kernel` adds (cambrian_amd/csrc/gemm_p4.hip, gemm_p4_epilogue.inc), restated
+"""CPU check of the address arithmetic `gemm_nt_p5_kernel` adds (cambrian_amd/csrc/gemm_p5.hip, gemm_p5_epilogue.inc), restated
 lane by lane: (a) the LDS-DMA pieces of a tile cover every (row, 16-byte chunk) of an operand buffer exactly once and put
 logical chunk c of row r where the fragment reads look for it; (b) the fragment reads of a wave are bank-conflict-free under
 the ds_read_b128 service model of MI355X_MICROARCH.md (16 lanes per pass over 64 banks x 4 B); (c) the epilogue's staging

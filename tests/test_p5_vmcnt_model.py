@@ -1,5 +1,5 @@
-"""CPU model of the hand-counted vector-memory waits of `gemm_nt_p5_kernel` (cambrian_amd/csrc/gemm_p4.hip) and of its
-epilogue's residual loads (gemm_p4_epilogue.inc).  A wave's vector-memory operations retire IN ORDER on gfx9 and
+"""CPU model of the hand-counted vector-memory waits of `gemm_nt_p5_kernel` (cambrian_amd/csrc/gemm_p5.hip) and of its
+epilogue's residual loads (gemm_p5_epilogue.inc).  A wave's vector-memory operations retire IN ORDER on gfx9 and
 `s_waitcnt vmcnt(N)` returns when at most N are outstanding, so a wait is correct iff everything it needs is older than
 the N youngest operations issued before it.  The model replays one wave's issue order over several items (persistent
 cursor: the last two tiles of an item stage the first two of the next) with the slot numbers and wait constants READ
@@ -12,18 +12,17 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = open(os.path.join(ROOT, "cambrian_amd", "csrc", "gemm_p4.hip")).read()
-EPI = open(os.path.join(ROOT, "cambrian_amd", "csrc", "gemm_p4_epilogue.inc")).read()
+SRC = open(os.path.join(ROOT, "cambrian_amd", "csrc", "gemm_p5.hip")).read()
+EPI = open(os.path.join(ROOT, "cambrian_amd", "csrc", "gemm_p5_epilogue.inc")).read()
 
 
 def consts():
     m = re.search(r'if \(rl\) asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\((\d+) \+ (\d+)\)', SRC)
     relaxed = int(m.group(1)) + int(m.group(2))
-    strict = int(re.search(r'else asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\((\d+)\) : "memory"\);\n\s+P4_BARRIER\(\);\n\s+\}\n\s+\} else \{', SRC).group(1))
-    a = re.search(r"L >= (\d+) && L <= (\d+) && \(\(L - \d+\) % (\d+)\) == 0 && !kNoDma\)\s+// A-row pieces", SRC)
-    b = re.search(r"L >= (\d+) && L <= (\d+) && \(\(L - \d+\) % (\d+)\) == 0 && !kNoDma\)\s+// B-row pieces", SRC)
-    kb = re.search(r"constexpr int kB1 = (\d+), kB2 = kB1 \+ (\d+)", SRC)
-    kb2 = int(kb.group(1)) + int(kb.group(2))
+    strict = int(re.search(r'else asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\((\d+)\) : "memory"\);\n\s+P4_BARRIER\(\);\n\s+\}\n\s+if constexpr \(L == 63\) advance', SRC).group(1))
+    a = re.search(r"L >= (\d+) && L <= (\d+) && \(\(L - \d+\) % (\d+)\) == 0\)\s+// A-row pieces", SRC)
+    b = re.search(r"L >= (\d+) && L <= (\d+) && \(\(L - \d+\) % (\d+)\) == 0\)\s+// B-row pieces", SRC)
+    kb2 = int(re.search(r"constexpr int kB2 = (\d+),", SRC).group(1))
     pro = int(re.search(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)" ::: "memory"\);\n\s+P4_BARRIER\(\);\n#pragma unroll\n\s+for \(int w = 0; w < 8; \+\+w\) read_frag\(0, 0u', SRC).group(1))
     slots = [s for s in range(int(a.group(1)), int(a.group(2)) + 1, int(a.group(3)))] + \
             [s for s in range(int(b.group(1)), int(b.group(2)) + 1, int(b.group(3)))]

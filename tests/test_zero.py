@@ -115,3 +115,25 @@ def test_zero2_single_process_equals_adamw():
         o2.step()
     for a, b in zip(m.parameters(), m2.parameters()):
         assert torch.allclose(a, b, atol=1e-7, rtol=1e-6)
+
+
+def test_zero2_skipped_step_leaves_no_stale_gradients():
+    """backward -> zero_grad() WITHOUT step() (a skipped non-finite step) must reset the buckets: the next
+    backward neither raises nor adds to the skipped gradients."""
+    from cambrian_amd.train.zero import Zero2AdamW
+    m = _model()
+    opt = Zero2AdamW(list(m.parameters()), lr=1e-2, weight_decay=0.1)
+    (m(_data(1, 7)[0]).pow(2).mean() * 1e3).backward()      # the step that gets skipped
+    opt.zero_grad()
+    with opt.no_sync():                                     # ... and the same under accumulation
+        (m(_data(1, 8)[0]).pow(2).mean() * 1e3).backward()
+    opt.zero_grad()
+    m(_data(1, 0)[0]).pow(2).mean().backward()
+    opt.step()
+    opt.zero_grad()
+    m2 = _model()
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-2, weight_decay=0.1)
+    m2(_data(1, 0)[0]).pow(2).mean().backward()
+    o2.step()
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.allclose(a, b, atol=1e-7, rtol=1e-6)

@@ -52,7 +52,13 @@ def _reference(world, steps):
     return [[p.detach().clone() for p in b.parameters()] for b in blocks]
 
 
-def _worker(rank, world, port, q):
+EXPECTED_LOG = [  # one step of the 3-unit chain (unit 1 frozen) with prefetch: each neighbour's all-gather is issued while
+    # the current unit is resident, and consumed by a wait instead of a blocking gather
+    ("gather", 0), ("prefetch", 1), ("release", 0), ("wait", 1), ("prefetch", 2), ("release", 1), ("wait", 2), ("release", 2),
+    ("gather", 2), ("prefetch", 1), ("release", 2), ("wait", 1), ("prefetch", 0), ("release", 1), ("wait", 0), ("release", 0)]
+
+
+def _worker(rank, world, port, q, prefetch=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from cambrian_amd.train.dp import init_distributed
@@ -61,15 +67,23 @@ def _worker(rank, world, port, q):
     blocks = _blocks()
     for p in blocks[1].parameters():
         p.requires_grad_(False)
-    units = zero3_wrap(blocks)
+    units = zero3_wrap(blocks, prefetch=prefetch)
+    log = []
+    for u in units:
+        u.log = log
     ok = all(not u.resident for u in units)                       # nothing is resident outside a forward / backward
     ok = ok and units[0].shard.numel() * world >= sum(p.numel() for p in blocks[0].parameters())
     opt = torch.optim.AdamW(zero3_parameters(units), lr=1e-2, weight_decay=0.1)
     steps = 3
     for step in range(steps):
+        del log[:]
         _run(blocks, _data(world, step)[rank]).backward()
         ok = ok and all(not u.resident for u in units)
         ok = ok and units[1].shard.grad is None and not units[1].trainable
+        if prefetch:
+            ok = ok and log == EXPECTED_LOG
+        else:
+            ok = ok and not any(w in ("prefetch", "wait") for w, _ in log)
         opt.step()
         opt.zero_grad()
     want = _reference(world, steps)
@@ -81,11 +95,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_zero3_world2_gloo():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("prefetch", [True, False])
+def test_zero3_world2_gloo(prefetch):
+    """Same parameters after 3 steps as unsharded AdamW on the rank-averaged gradients, with the one-unit-ahead
+    all-gather prefetch (asynchronous collectives; the order of the collectives is asserted) and without it."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, prefetch)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
@@ -161,3 +181,33 @@ def test_zero3_units_opt_out_of_frozen_weight_caches():
     assert "_w_qkv" not in att.__dict__                                      # dropped at wrap time
     assert CL._fused_frozen_weight(att, "_w_qkv", (att.q_proj, att.k_proj, att.v_proj)) is None
     assert all(m.__dict__.get("_cmb_no_weight_cache") for m in layer.modules())
+
+
+def test_zero3_backward_starts_from_any_output():
+    """the gather hook sits on EVERY output tensor that requires grad and runs once per backward — a unit whose
+    first output is not differentiable (or not used by the loss) still gathers, reduces and releases."""
+    from cambrian_amd.train.zero3 import zero3_finalize, zero3_wrap
+
+    class TwoOut(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(8, 8)
+
+        def forward(self, x):
+            return x.detach().sum(), self.a(x), self.a(x) * 2.0     # (no grad, grad, grad)
+
+    torch.manual_seed(0)
+    m = TwoOut()
+    ref = torch.nn.Linear(8, 8)
+    ref.load_state_dict(m.a.state_dict())
+    (u,) = zero3_wrap([m])
+    x = torch.randn(4, 8)
+    for _ in range(2):                                              # two steps: the per-backward flag is re-armed
+        u.shard.grad = None
+        _, y1, y2 = m(x)
+        (y1.pow(2).mean() + y2.mean()).backward()
+        zero3_finalize([u])
+        assert not u.resident and u.shard.grad is not None
+    (ref(x).pow(2).mean() + (ref(x) * 2.0).mean()).backward()
+    want = torch.cat([ref.weight.grad.reshape(-1), ref.bias.grad.reshape(-1)])
+    assert torch.allclose(u.shard.grad[: want.numel()], want, atol=1e-6)

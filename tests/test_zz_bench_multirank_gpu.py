@@ -30,3 +30,20 @@ def test_two_ranks_one_json_line(dev, mode):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     assert d["value"] == pytest.approx(4 / (d["ms_per_step"] * 1e-3), rel=1e-6)    # whole-job images / max-over-ranks time
     assert ("zero3" in d["config"]["parallelism"]) == bool(mode)
+
+
+def test_plain_launch_spawns_its_own_ranks(dev):
+    """VERDICT r2 missing #1: `python bench.py --gpus 2` WITHOUT torchrun (how the driver starts the N = 1 run) must not
+    die on the world-size check: bench.py re-launches itself under torch.distributed.run and relays rank 0's line."""
+    env = dict(os.environ, CAMBRIAN_DIST_BACKEND="gloo", CAMBRIAN_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               CAMBRIAN_AMD_RANDOM_INIT="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2",
+           "--llm-layers", "2", "--no-cpu-baseline", "--no-masked-case", "--no-ab", "--no-gemm-pass"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4

@@ -4,9 +4,12 @@ The decoder's GEMMs are not part of the hand-written hot path (north star: LLM d
 of the step, and PyTorch's default heuristic picks a forward (TN) solution that runs at ~1.28 PFLOP/s where the library
 holds one at 1.6-1.9 PFLOP/s.  ``tools/tune_llm_gemms.py`` runs PyTorch's own TunableOp search once on an MI355X for
 the ten shapes of Llama-3-8B at 16 images x 2048 tokens per GPU and stores the winners in
-``cambrian_amd/tunableop/llama3_8b_b16_gfx950.csv``; this module only LOADS that file (tuning disabled: nothing is
+``tools/llm_gemm_tuning/llama3_8b_b16_gfx950.csv``; this module only LOADS that file (tuning disabled: nothing is
 searched at run time, unknown shapes fall back to the default heuristic, a file from another ROCm / hipBLASLt build is
-rejected by TunableOp's validators and ignored)."""
+rejected by TunableOp's validators and ignored).
+
+A round-1 experiment kept under tools/: measured neutral in the step (the default heuristic's picks are as fast under
+sustained load), so no product code imports it."""
 from __future__ import annotations
 
 import os
@@ -15,7 +18,7 @@ import tempfile
 
 import torch
 
-_CSV = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tunableop", "llama3_8b_b16_gfx950.csv")
+_CSV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "llama3_8b_b16_gfx950.csv")
 
 
 def load_tuned_llm_gemms(path: str = _CSV) -> bool:

@@ -1,6 +1,6 @@
 """Tune (PyTorch TunableOp) the hipBLASLt / rocBLAS solution of the frozen Llama-3-8B projection GEMMs at the bench
-shape (M = 16 images x 2048 tokens) and append to cambrian_amd/tunableop/llama3_8b_b16_gfx950.csv, which bench.py loads
-with tuning DISABLED (so the driver's run pays nothing).  Usage: python tools/tune_llm_gemms.py [M] (GPU box)."""
+shape (M = 16 images x 2048 tokens) and append to tools/llm_gemm_tuning/llama3_8b_b16_gfx950.csv (load_tuned.py reads it; a round-1 experiment)
+with tuning DISABLED (so the driver's run pays nothing).  Usage: python tools/llm_gemm_tuning/tune_llm_gemms.py [M] (GPU box)."""
 import os
 import sys
 import time
@@ -8,8 +8,7 @@ import time
 import torch
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-path = os.path.join(here, "cambrian_amd", "tunableop", "llama3_8b_b16_gfx950.csv")
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "llama3_8b_b16_gfx950.csv")
 t = torch.cuda.tunable
 t.enable(True)
 t.tuning_enable(True)
