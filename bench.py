@@ -503,9 +503,10 @@ def main():
     # timed region, where ~1200 extra event pairs per step would cost the stream about half a percent
     prof_all = None
     gemm_pass_steps = 2
-    if prof is not None and not args.no_gemm_pass:
-        prof_all = ops.GEMM_PROFILE = []
-        ops.GEMM_PROFILE_TILE = 0
+    if not args.no_roofline and not args.no_gemm_pass:   # EVERY rank steps (the steps carry collectives); rank 0 records
+        if rank == 0:
+            prof_all = ops.GEMM_PROFILE = []
+            ops.GEMM_PROFILE_TILE = 0
         for _ in range(gemm_pass_steps):
             step()
         torch.cuda.synchronize()

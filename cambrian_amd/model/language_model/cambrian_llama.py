@@ -14,6 +14,8 @@ transformers 5.x, so the loop is re-stated here with HF-compati
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import List, Optional, Tuple
 
@@ -89,18 +91,28 @@ class FrozenLinearFn(torch.autograd.Function):
     one more resident copy of the frozen weights (15 GB of the 288 GB for Llama-3-8B)."""
 
     @staticmethod
-    def forward(ctx, x2, w, w_t, res2):
-        """2-D in, 2-D out (fresh tensor): callers reshape outside, so later in-place users of the result (the SVA hook's
-        scatter, the fused cross-entropy writing dlogits over the logits) never touch a view made inside a Function."""
+    def forward(ctx, x2, w, w_t, res2, out_shape):
+        """2-D operands, result written into a FRESH tensor of the caller's N-D ``out_shape`` (the GEMM's ``out=`` is its
+        2-D view; no autograd is recorded in here).  The result is therefore NOT a view: the SVA hook's in-place scatter
+        into a decoder layer's output stays a plain in-place op — on a ``y2d.view(B, S, H)`` made outside, autograd wraps
+        it in CopySlices (a clone and a copy of [B, S, H] per hook in the backward, and the gradient tensor the hook's
+        scatter returns is no longer the one the layer receives)."""
         ctx.save_for_backward(w_t)
         ctx.has_res = res2 is not None
-        return F.linear(x2, w) if res2 is None else torch.addmm(res2, x2, w.t())
+        out = torch.empty(out_shape, dtype=x2.dtype, device=x2.device)
+        o2 = out.view(-1, w.shape[0])
+        if res2 is None:
+            torch.mm(x2, w.t(), out=o2)
+        else:
+            torch.addmm(res2, x2, w.t(), out=o2)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         (w_t,) = ctx.saved_tensors
-        dx = F.linear(g, w_t) if ctx.needs_input_grad[0] else None
-        return dx, None, None, (g if ctx.has_res else None)
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = F.linear(g2, w_t) if ctx.needs_input_grad[0] else None
+        return dx, None, None, (g2 if ctx.has_res else None), None
 
 
 def _frozen_transposed(owner: nn.Module, key: str, w: torch.Tensor) -> torch.Tensor:
@@ -122,9 +134,9 @@ def frozen_linear(owner: nn.Module, key: str, x: torch.Tensor, w: torch.Tensor, 
     x2 = x.reshape(-1, x.shape[-1])
     res2 = None if residual is None else residual.reshape(-1, w.shape[0])
     if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
-        y = FrozenLinearFn.apply(x2, w, _frozen_transposed(owner, key, w), res2)
-    else:   # eval / generate: nothing will be back-propagated, so no transposed copy is made or kept
-        y = F.linear(x2, w) if res2 is None else torch.addmm(res2, x2, w.t())
+        return FrozenLinearFn.apply(x2, w, _frozen_transposed(owner, key, w), res2, (*x.shape[:-1], w.shape[0]))
+    # eval / generate: nothing will be back-propagated, so no transposed copy is made or kept
+    y = F.linear(x2, w) if res2 is None else torch.addmm(res2, x2, w.t())
     return y.view(*x.shape[:-1], w.shape[0])
 
 
@@ -251,7 +263,9 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = HipRMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device, dtype)
 
     def forward(self, x, cos, sin, attn_mask, kv_out: Optional[list] = None):
-        a = self.self_attn(self.input_layernorm(x), cos, sin, attn_mask, kv_out)
+        n1 = self.input_layernorm
+        x, xn = ops.rmsnorm_fork(x, n1.weight, n1.variance_epsilon)   # (skip path, attention input): one backward node
+        a = self.self_attn(xn, cos, sin, attn_mask, kv_out)
         n2 = self.post_attention_layernorm
         x, h = ops.add_rmsnorm(x, a, n2.weight, n2.variance_epsilon)  # x + a and norm(x + a) in one pass
         return self.mlp(h, residual=x)
@@ -358,7 +372,7 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
         side = int(cfg.image_token_len ** 0.5)
         hidden = hidden if hidden.is_contiguous() else hidden.contiguous()
         span = ops.region_begin("sva_in_llm")                                          # (bench.py roofline.region)
-        link = {}                                                                      # gather / scatter share d(hidden)
+        link = None if os.environ.get("CAMBRIAN_AMD_NO_HOOK_LINK") else {}             # gather / scatter share d(hidden)
         q2 = ops.gather_query_rows(hidden, p0, side, link)                             # [B*576, H]
         q2 = ops.region_mark(q2, span, "b1")
         feats = [f if f.dtype == q2.dtype else f.to(q2.dtype) for f in sva.feats]      # :186

@@ -112,7 +112,9 @@ class Phi3DecoderLayer(nn.Module):
         self.post_attention_layernorm = HipRMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device, dtype)
 
     def forward(self, x, cos, sin, attn_mask, kv_out: Optional[list] = None):
-        a = self.self_attn(self.input_layernorm(x), cos, sin, attn_mask, kv_out)
+        n1 = self.input_layernorm
+        x, xn = ops.rmsnorm_fork(x, n1.weight, n1.variance_epsilon)   # (skip path, attention input): one backward node
+        a = self.self_attn(xn, cos, sin, attn_mask, kv_out)
         n2 = self.post_attention_layernorm
         x, h = ops.add_rmsnorm(x, a, n2.weight, n2.variance_epsilon)              # :903-911 residual + norm, one pass
         return self.mlp(h, residual=x)

@@ -178,6 +178,7 @@ def test_end_to_end_logits_loss_and_gradients(dev, monkeypatch, name, dt, tol_lo
     assert abs(out.loss.item() - ref_loss.item()) < tol_logits * max(1.0, abs(ref_loss.item()))
     worst = ("", 0.0)
     n_checked = 0
+    bad_slope = []
     for n, q in model.named_parameters():
         if not q.requires_grad:
             assert q.grad is None
@@ -191,7 +192,10 @@ def test_end_to_end_logits_loss_and_gradients(dev, monkeypatch, name, dt, tol_lo
         if err > worst[1]:
             worst = (n, err)
         if g_ref.numel() >= 4096:     # big tensors: the slope of the gradient is pinned to 1 % even in bf16
-            assert fit_err(q.grad, g_ref)[0] < (1e-3 if name == "fp32" else 1e-2), (n, fit_err(q.grad, g_ref))
+            fe = fit_err(q.grad, g_ref)
+            if not fe[0] < (1e-3 if name == "fp32" else 1e-2):
+                bad_slope.append((n, round(fe[0], 4), round(fe[1], 4), round(err, 4)))
+    assert not bad_slope, f"{len(bad_slope)} of {n_checked} gradient tensors off in slope: {bad_slope[:12]}"
     assert n_checked > 50
     assert worst[1] < tol_grad, f"worst trainable-parameter gradient {worst}"
 
