@@ -314,6 +314,57 @@ static int choose_bf16_kernel(const GemmParams& p, int splits, int hint, int* sc
   return 256;
 }
 
+// Tail split (round 3).  A 256 x 256 grid of T tiles takes ceil(T / CUs) rounds; when T is a little more than a whole
+// number of rounds the last round runs a handful of tiles on an otherwise idle chip (DINOv2's 11680 x 1536 GEMMs: 46 x 6
+// = 276 tiles = 2 rounds for 1.08 rounds of work; SigLIP's 11664 x 4352: 782 tiles = 4 rounds for 3.05).  Such a problem
+// is launched as two row ranges: the first m1 row tiles (as many whole rounds as fit) on the 256-tile kernel the cost
+// model picks for them, the remaining rows on the 128 x 128 kernel (two workgroups per CU, any epilogue), whose partial
+// round is much shorter than a 256-tile round.  Cost model in 256-tile rounds: the 128-tile kernel runs ~1.6x longer per
+// FLOP (profiles/r02_gemm_lab.md), 0.1 round for the extra launch; taken when it saves more than 7 %.  Row maps must be
+// linear across the cut (identity, or the cut a multiple of the outer period).  Returns the rows of the first range or 0.
+static int device_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n <= 0)
+      n = 256;
+    n -= n % 8;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+static bool tail_split_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CMB_GEMM_NO_TAIL_SPLIT");
+    v = (e && atoi(e)) ? 0 : 1;
+  }
+  return v != 0;
+}
+static bool map_linear_at(const RowMap& m, int64_t row) { return m.n1 == 0 || row % m.n1 == 0; }
+static int tail_split_rows_mnk(int64_t M, int64_t N) {
+  if (!tail_split_enabled() || N % 256 != 0) return 0;
+  const int64_t tm = (M + 255) / 256, tn = N / 256, T = tm * tn;
+  const int64_t ncu = device_cus();
+  if (T <= ncu) return 0;
+  const int64_t m1 = ((T / ncu) * ncu) / tn;   // row tiles that fill whole rounds
+  if (m1 <= 0 || m1 >= tm) return 0;
+  const int64_t tail = T - m1 * tn;
+  const double now = (double)((T + ncu - 1) / ncu);
+  const double hyb = (double)((m1 * tn + ncu - 1) / ncu) + 1.6 * (double)tail / (double)ncu + 0.1;
+  return hyb < 0.93 * now ? (int)(m1 * 256) : 0;
+}
+static int tail_split_rows(const GemmParams& p, int splits, int hint) {
+  if (hint || tile_override() || splits > 1 || p.slabs || p.a_scale || p.b_scale) return 0;
+  const int m1 = tail_split_rows_mnk(p.M, p.N);
+  if (!m1) return 0;
+  if (!map_linear_at(p.a_map, m1) || !map_linear_at(p.c_map, m1) || (p.R && !map_linear_at(p.r_map, m1)) ||
+      (p.P && !map_linear_at(p.p_map, m1)))
+    return 0;
+  return m1;
+}
+
 template <typename T>
 int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   constexpr int BK = 128 / (int)sizeof(T);
@@ -358,11 +409,26 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   int rc;
   if constexpr (sizeof(T) == 2) {
     int sched = 0;
-    const int kern = choose_bf16_kernel(p, splits, d->tile_hint, &sched);
-    g_last_kernel = kern;
-    if (kern == 128) rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
-    else if (kern == 2590) rc = launch_gemm_p5_bf16(p, splits, s);
-    else rc = launch_gemm256_bf16(p, splits, sched, s);
+    const int m1 = tail_split_rows(p, splits, d->tile_hint);
+    if (m1) {
+      GemmParams head = p, tail = p;
+      head.M = m1;
+      tail.M = p.M - m1;
+      tail.A += row_off(p.a_map, (uint32_t)m1) * 2;
+      tail.C += row_off(p.c_map, (uint32_t)m1) * (p.out_f32 ? 4 : 2);
+      if (p.R) tail.R += row_off(p.r_map, (uint32_t)m1) * 2;
+      if (p.P) tail.P += row_off(p.p_map, (uint32_t)m1) * 2;
+      const int kern = choose_bf16_kernel(head, 1, 256, &sched);   // (256: the 256-tile branch of the cost model, no policy)
+      g_last_kernel = kern;
+      rc = kern == 2590 ? launch_gemm_p5_bf16(head, 1, s) : launch_gemm256_bf16(head, 1, sched, s);
+      if (rc == CMB_OK) rc = launch_gemm<T, 128, 128, 2, 2>(tail, 1, s);
+    } else {
+      const int kern = choose_bf16_kernel(p, splits, d->tile_hint, &sched);
+      g_last_kernel = kern;
+      if (kern == 128) rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
+      else if (kern == 2590) rc = launch_gemm_p5_bf16(p, splits, s);
+      else rc = launch_gemm256_bf16(p, splits, sched, s);
+    }
   } else {
     g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, splits, s);
   }
@@ -409,6 +475,8 @@ extern "C" int cmb_gemm_policy_clear(void) {
 }
 
 extern "C" int cmb_gemm_last_kernel(void) { return g_last_kernel; }
+
+extern "C" int64_t cmb_gemm_tail_rows(int64_t M, int64_t N) { return tail_split_rows_mnk(M, N); }
 
 extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return CMB_ERR_BAD_ARG;

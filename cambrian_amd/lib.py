@@ -93,6 +93,7 @@ SIGNATURES = {
     "cmb_gemm_last_kernel": (C.c_int, []),
     "cmb_gemm_policy_set": (C.c_int, [_i64, _i64, _i64, _i32, _i32]),
     "cmb_gemm_policy_clear": (C.c_int, []),
+    "cmb_gemm_tail_rows": (_i64, [_i64, _i64]),
     "cmb_quantize_fp8_rows": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),

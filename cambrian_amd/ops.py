@@ -268,6 +268,8 @@ class gemm_census:
             tiles = ((M + 255) // 256) * (N // 256)
             if pre or N % 256 or K < 128 or K % 64 or tiles <= 256:
                 continue
+            if L.load().cmb_gemm_tail_rows(M, N):
+                continue   # launched as 256-tile head + 128-tile tail (gemm.hip "Tail split"): the policy does not apply
             rows.append((2.0 * M * N * K * cnt, (M, N, K, act)))
         rows.sort(reverse=True)
         return [r[1] for r in rows[:n]]

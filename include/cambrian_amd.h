@@ -124,6 +124,11 @@ int cmb_gemm_last_kernel(void);
  * faster for a shape varies from box to box — VERDICT r2 #4).  At most 64 entries (CMB_ERR_WORKSPACE beyond); not
  * thread-safe against concurrent cmb_gemm calls: set it between steps. */
 int cmb_gemm_policy_set(int64_t M, int64_t N, int64_t K, int32_t act, int32_t kernel);
+/* Tail split of bf16 launches without tile_hint / split-K (gemm.hip "Tail split"): when an M x N problem's 256 x 256 tile
+ * count is a little more than a whole number of rounds of the device's CUs, rows [0, m1) run on the 256-tile kernel and
+ * rows [m1, M) on the 128 x 128 kernel, two launches inside one cmb_gemm call.  Returns m1 (0 = launched whole).
+ * CMB_GEMM_NO_TAIL_SPLIT=1 in the environment disables it (A/B runs). */
+int64_t cmb_gemm_tail_rows(int64_t M, int64_t N);
 int cmb_gemm_policy_clear(void);
 
 /* out[C, R_pad] = in[R, C]^T, zero-filling columns R..R_pad-1 (R_pad >= R). Used to put the

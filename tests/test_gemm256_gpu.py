@@ -182,3 +182,56 @@ def test_default_dispatch_reports_its_kernel(dev):
         outs[(M, N, K)] = out
     a, w = torch.randn(4096, 512, generator=g).to(dev, dt), (torch.randn(1024, 512, generator=g) * 0.2).to(dev, dt)
     assert torch.equal(ops.k_gemm(a, w, tile=2590), ops.k_gemm(a, w, tile=2560))   # same MFMA order, same rounding
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(11680, 1536, 1536, "plain"), (11664, 4352, 1152, "bias_gelu_res"),
+                                         (9232, 4096, 1024, "bias_quick_cs"), (11680, 1536, 4096, "f32out"),
+                                         (16896, 4096, 256, "rowmap4096"), (16896, 4096, 256, "rowmap4224")])
+def test_tail_split_is_the_same_gemm(dev, M, N, K, mode):
+    """gemm.hip "Tail split": a default-dispatch launch whose 256-tile count is a little more than whole rounds runs as a
+    256-tile head + a 128-tile tail (two launches, one cmb_gemm call).  Same result as the single-kernel launches, for
+    every epilogue, fp32 output, and a row map whose outer period divides the cut."""
+    ops, L = _ops()
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    dt = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dt).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dt).to(dev)
+    kw, ref = {}, a.float() @ w.float().T
+    if "bias" in mode:
+        b = torch.randn(N, generator=g).to(dev)
+        kw["bias"], ref = b, ref + b
+    if "gelu" in mode:
+        kw["act"], ref = L.ACT_GELU_ERF, F.gelu(ref)
+    if "quick" in mode:
+        kw["act"], ref = L.ACT_QUICK_GELU, ref * torch.sigmoid(1.702 * ref)
+    if "cs" in mode:
+        cs = torch.randn(N, generator=g).to(dev)
+        kw["colscale"], ref = cs, ref * cs
+    if "res" in mode:
+        r = torch.randn(M, N, generator=g).to(dt).to(dev)
+        kw["residual"], ref = r, ref + r.float()
+    if mode == "f32out":
+        kw["out_dtype"] = torch.float32
+    if mode.startswith("rowmap"):
+        # A rows gathered from a [nb, T + 7, K] buffer through a row map of outer period T.  The cut (16384 rows) is a
+        # multiple of T = 4096 (-> split, the tail's base pointer is the mapped row) but not of 4224 (-> launched whole).
+        T = int(mode[6:])
+        nb = (M + T - 1) // T
+        buf = torch.randn(nb, T + 7, K, generator=g).to(dt).to(dev)
+        a = buf[:, :T].reshape(nb * T, K)[:M].contiguous()
+        ref = a.float() @ w.float().T
+        kw.update(M=M, a_map=L.make_map(T, 1, (T + 7) * K, 0, K))
+        out = ops.k_gemm(buf.view(-1), w, **kw)
+        whole = ops.k_gemm(a, w, tile=2560)
+        assert rel_err(out, ref) < 1e-2 and rel_err(out, whole.float()) < 8e-3
+        return
+    m1 = lib.cmb_gemm_tail_rows(M, N)
+    assert m1 > 0 and m1 % 256 == 0 and m1 < M, (M, N, m1)
+    out = ops.k_gemm(a, w, **kw)                          # default dispatch: head + tail
+    assert lib.cmb_gemm_last_kernel() in (256, 2590)
+    whole = ops.k_gemm(a, w, tile=2560, **kw)             # one 8-wave launch over all rows
+    tol = 2e-5 if mode == "f32out" else 1e-2
+    assert rel_err(out, ref) < tol and rel_err(whole, ref) < tol
+    assert torch.equal(out[:m1], whole[:m1])              # the head rows: same 256-tile arithmetic, bit for bit
+    assert rel_err(out[m1:], whole[m1:].float()) < (2e-5 if mode == "f32out" else 8e-3)
