@@ -315,7 +315,7 @@ PARITY = {
 }
 
 
-PMC_FILES = {2590: "r02_pmc_gemm_p5.json", 256: "pmc_gemm256.json"}   # cmb_gemm_last_kernel id -> profiles/ file
+PMC_FILES = {2590: "r03_pmc_gemm_p5.json", 256: "r03_pmc_gemm_8wave.json"}   # cmb_gemm_last_kernel id -> profiles/ file
 
 
 def pmc_record(kernel_id):

@@ -221,7 +221,7 @@ def test_tail_split_is_the_same_gemm(dev, M, N, K, mode):
         buf = torch.randn(nb, T + 7, K, generator=g).to(dt).to(dev)
         a = buf[:, :T].reshape(nb * T, K)[:M].contiguous()
         ref = a.float() @ w.float().T
-        kw.update(M=M, a_map=L.make_map(T, 1, (T + 7) * K, 0, K))
+        kw.update(M=M, a_map=L.make_map(T, T, (T + 7) * K, 0, K))   # row r -> (r // T) * (T + 7) * K + (r % T) * K
         out = ops.k_gemm(buf.view(-1), w, **kw)
         whole = ops.k_gemm(a, w, tile=2560)
         assert rel_err(out, ref) < 1e-2 and rel_err(out, whole.float()) < 8e-3

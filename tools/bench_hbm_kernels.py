@@ -46,12 +46,12 @@ def cases():
     # ---- SVA shared-statistics normalisation (x + pos -> xhat, statistics kept): the ConvNeXt tower's 9216 tokens / image
     rows, D = B * 9216, 1024
 
-    def mk_svan():
+    def mk_svan(rows=rows, D=D):
         x, pos = rn(rows, D), rn(16, D, dtype=f32)
         return lambda: ops.k_layernorm_fwd(x, None, None, 1e-5, add=pos, side=96, grid_r=4)
     add("layernorm_fwd [SVA xhat, ConvNeXt tower]", "layernorm_fwd_kernel", f"{rows}x{D}", rows * D * 2 * 2 + rows * 8, mk_svan)
 
-    def mk_svanb():
+    def mk_svanb(rows=rows, D=D):
         x, dn, pos = rn(rows, D), rn(rows, D), rn(16, D, dtype=f32)
         _, mean, rstd = ops.k_layernorm_fwd(x, None, None, 1e-5, add=pos, side=96, grid_r=4)
         acc = torch.zeros(rows, D, device=dev, dtype=f32)
@@ -60,7 +60,7 @@ def cases():
     add("layernorm_bwd [SVA, fp32 accumulate, ConvNeXt tower]", "layernorm_bwd_kernel<.., true>", f"{rows}x{D}",
         rows * D * (2 + 2 + 4 + 4) + rows * 8, mk_svanb)
 
-    def mk_lnb():
+    def mk_lnb(D=D):
         r2 = B * 576
         x, dy, g = rn(r2, D), rn(r2, D), rn(D, dtype=f32)
         _, mean, rstd = ops.k_layernorm_fwd(x, g, g, 1e-5)
@@ -90,7 +90,7 @@ def cases():
     # ---- RMSNorm family (decoder side, 16 x 2048 tokens x 4096)
     rows, D = B * 2048, 4096
 
-    def mk_rms():
+    def mk_rms(rows=rows, D=D):
         x, w = rn(rows, D), rn(D, dtype=f32)
         y, rstd = torch.empty_like(x), torch.empty(rows, device=dev, dtype=f32)
         lib = L.load()
@@ -98,7 +98,7 @@ def cases():
                                                    L.stream_ptr(dev)), "rmsnorm_fwd")
     add("rmsnorm_fwd", "rmsnorm_fwd_kernel", f"{rows}x{D}", rows * D * 2 * 2, mk_rms)
 
-    def mk_addrms():
+    def mk_addrms(rows=rows, D=D):
         x, d_, w = rn(rows, D), rn(rows, D), rn(D, dtype=f32)
         s, y, rstd = torch.empty_like(x), torch.empty_like(x), torch.empty(rows, device=dev, dtype=f32)
         lib = L.load()
@@ -106,7 +106,7 @@ def cases():
                                                        y.data_ptr(), rstd.data_ptr(), L.stream_ptr(dev)), "add_rmsnorm")
     add("add_rmsnorm_fwd", "add_rmsnorm_fwd_kernel", f"{rows}x{D}", rows * D * 2 * 4, mk_addrms)
 
-    def mk_rmsb():
+    def mk_rmsb(rows=rows, D=D):
         x, dy, gs, w = rn(rows, D), rn(rows, D), rn(rows, D), rn(D, dtype=f32)
         rstd, dx = torch.rand(rows, device=dev, dtype=f32), torch.empty_like(x)
         lib = L.load()
