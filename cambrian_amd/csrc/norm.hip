@@ -25,6 +25,19 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int nvec = D >> 3;
+  // the affine parameters live in registers across the wave's rows (re-loading 2 x 4 D bytes of fp32 per 2 D-byte row
+  // put 4x the row's own bytes through the vector cache: 3.6-4.0 TB/s against 4.8 for the non-affine SVA variant)
+  float gg[NCH][8], bb[NCH][8];
+  if (gamma) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        load8f(gamma + vi * 8, gg[c]);
+        load8f(beta + vi * 8, bb[c]);
+      }
+    }
+  }
   for (int64_t row = wave_global; row < rows; row += nwaves) {
     float v[NCH][8];
     const T* xr = x + row * ldx;
@@ -68,11 +81,8 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
         if (gamma) {
-          float gg[8], bb[8];
-          load8f(gamma + vi * 8, gg);
-          load8f(beta + vi * 8, bb);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = o[e] * gg[e] + bb[e];
+          for (int e = 0; e < 8; ++e) o[e] = o[e] * gg[c][e] + bb[c][e];
         }
         Vec8<T>::store(yr + vi * 8, o);
       }
@@ -502,7 +512,11 @@ int ln_fwd(const void* x, int64_t rows, int64_t D, int64_t ldx, const float* add
            const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd,
            hipStream_t s) {
   const int nch = nch_for(D);
-  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,
+  // at most 2048 workgroups (= 8192 waves, the chip's resident-wave capacity): a wave then walks several rows with its
+  // affine parameters in registers
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3((unsigned)blocks), dim3(256), 0, s,
                                        (const T*)x, rows, (int)D, ldx, add, side, grid_r, gamma, beta, eps,
                                        (T*)y, ldy, mean, rstd));
   CMB_CHECK_LAUNCH();
