@@ -59,10 +59,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAMBRIAN_BENCH_BATCH", "16")),
-                    help="images per GPU per step.  The reference runs per_device_train_batch_size 8 on 32 GB TPU-v4 cores "
-                         "(pretrain_cambrian_8b.sh:37); 16 uses 156 of the MI355X's 288 GB (no activation re-computation) and "
-                         "fills the chip better on the towers' mid-size GEMMs (+4 % images/s over 8; 32 = 278 GB, too close)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CAMBRIAN_BENCH_BATCH", "0")),
+                    help="images per GPU per step (0 = default: 24 on a 288 GB MI355X, else 16).  The reference runs "
+                         "per_device_train_batch_size 8 on 32 GB TPU-v4 cores (pretrain_cambrian_8b.sh:37); no activation "
+                         "re-computation here: 16 images use 170 GB, 24 use 231 GB of the 288 GB and fill the chip better on the "
+                         "towers' mid-size GEMMs (same box: 14.67 / 14.74 / 14.88 images/s at 16 / 20 / 24; 32 does not fit).  A "
+                         "single-GPU run that hits out-of-memory in its first step falls back to 16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--zero2", action="store_true", help="ZeRO-2 (reduce-scatter grads, sharded AdamW, all-gather params: BASELINE "
                     "config 4's partitioning) instead of all-reduce + replicated AdamW")
@@ -422,15 +424,22 @@ def main():
     else:
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
         sync = GradSync(params)
+    if args.batch <= 0:   # default: what fits the device with headroom
+        total_gb = torch.cuda.get_device_properties(dev).total_memory / 2 ** 30
+        args.batch = 24 if (total_gb >= 280 and args.preset == "8b") else 16
     B = args.batch
     pos0 = cfg.image_position
-    batch = synthetic_batch(B, seed=1234 + rank, image_position=pos0)
-    kw = dict(input_ids=batch["input_ids"].to(dev), labels=batch["labels"].to(dev),
-              position_ids=batch["position_ids"].to(dev),
-              attention_mask=None,  # square synthetic images: nothing is padded -> plain causal attention
-              images=[i.to(dev, torch.bfloat16) for i in batch["images"]],
-              image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
-              image_sizes=batch["image_sizes"])
+
+    def make_inputs(nb):
+        batch = synthetic_batch(nb, seed=1234 + rank, image_position=pos0)
+        return dict(input_ids=batch["input_ids"].to(dev), labels=batch["labels"].to(dev),
+                    position_ids=batch["position_ids"].to(dev),
+                    attention_mask=None,  # square synthetic images: nothing is padded -> plain causal attention
+                    images=[i.to(dev, torch.bfloat16) for i in batch["images"]],
+                    image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
+                    image_sizes=batch["image_sizes"])
+
+    kw = make_inputs(B)
 
     feed = None
     if args.input_pipeline:
@@ -465,6 +474,22 @@ def main():
     # results either way).  The census step is the first warm-up step when there is one.
     calibration = None
     warm_left = args.warmup
+    batch_fallback = None
+    if world == 1 and B > 16:   # probe the chosen batch once; an out-of-memory first step falls back to 16 images
+        try:
+            step()
+            torch.cuda.synchronize()
+        except torch.OutOfMemoryError as e:
+            batch_fallback = f"{B} images did not fit ({str(e)[:120]}): fell back to 16"
+            opt.zero_grad(set_to_none=True)
+            model.zero_grad(set_to_none=True)
+            kw.clear()
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            B = args.batch = 16
+            kw.update(make_inputs(B))
+        warm_left = max(0, warm_left - 1)
     if not args.no_calibration and args.preset in PRESETS:
         with ops.gemm_census() as census:
             step()
@@ -559,8 +584,11 @@ def main():
                        "images_per_gpu": B, "global_batch": B * world, "seq_len": 2048,
                        "parallelism": f"dp{world}" + ("+zero2" if args.zero2 else "") + ("+zero3" if args.zero3 else ""),
                        "loss": float(loss.item()),
-                       "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30},
+                       "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+                       "peak_hbm_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30},
         }
+        if batch_fallback:
+            line["config"]["batch_fallback"] = batch_fallback
         if args.fp8_projections:
             line["dtype"] = "bf16 + fp8 (e4m3, row-wise scales) forward GEMMs of the KV-side SVA projections"
             line["config"]["NOT_HEADLINE"] = "reduced-precision mode of BASELINE configs[4]; the headline line is the bf16 run"

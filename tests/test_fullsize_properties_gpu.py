@@ -175,3 +175,22 @@ def test_towers_batch_independence_fullsize(dev):
         both, one = t(x), t(x[:1])
         assert torch.isfinite(both.float()).all()
         assert torch.equal(both[:1], one)
+
+
+def test_convnext_xxl_batch_24_has_no_index_overflow(dev):
+    """bench.py's default batch of 24 images makes ConvNeXt-XXL's stage-1 MLP intermediate 24 x 65536 x 1536 = 2.4e9
+    elements (> 2^31) and the aux-projector input 221184 x 5760: the same 24 images as two batches of 12 must give the same
+    features (row ranges of a GEMM may change kernels with the grid — tail split — so a few bf16 ulps, not bit equality),
+    and the last image — the highest addresses — is checked on its own."""
+    from types import SimpleNamespace
+    from conftest import rel_err
+    from cambrian_amd.model.multimodal_encoder.builder import build_vision_tower_aux_list
+    cfg = SimpleNamespace(mm_vision_tower_aux_list=["clip-convnext-XXL-multi-stage"], mm_vision_tower_aux_token_len_list=[9216],
+                          mm_vision_select_layer=-2, mm_vision_select_feature="patch", unfreeze_mm_vision_tower=False)
+    (t,) = build_vision_tower_aux_list(cfg)
+    x = torch.randn(24, 3, 1024, 1024, generator=torch.Generator().manual_seed(24)).to(dev, torch.bfloat16)
+    whole = t(x)
+    assert whole.shape == (24, 9216, 5760) and torch.isfinite(whole.float()).all()
+    halves = torch.cat([t(x[:12]), t(x[12:])], 0)
+    assert rel_err(whole, halves.float()) < 2e-2
+    assert rel_err(whole[23], halves[23].float()) < 2e-2 and rel_err(whole[23], t(x[23:24])[0].float()) < 2e-2
