@@ -483,6 +483,8 @@ def main():
             batch_fallback = f"{B} images did not fit ({str(e)[:120]}): fell back to 16"
             opt.zero_grad(set_to_none=True)
             model.zero_grad(set_to_none=True)
+            if sync is not None:
+                sync.reset()
             kw.clear()
             import gc
             gc.collect()

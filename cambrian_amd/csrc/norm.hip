@@ -27,10 +27,12 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(
   const int nvec = D >> 3;
   // the affine parameters live in registers across the wave's rows (re-loading 2 x 4 D bytes of fp32 per 2 D-byte row
   // put 4x the row's own bytes through the vector cache: 3.6-4.0 TB/s against 4.8 for the non-affine SVA variant)
-  float gg[NCH][8], bb[NCH][8];
-  if (gamma) {
+  // Only for rows of up to 1024 elements (NCH <= 2: 32 more registers); wider rows would give up waves per SIMD for it.
+  constexpr bool kHoist = NCH <= 2;
+  float gg[kHoist ? NCH : 1][8], bb[kHoist ? NCH : 1][8];
+  if (kHoist && gamma) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < (kHoist ? NCH : 1); ++c) {
       const int vi = lane + c * 64;
       if (vi < nvec) {
         load8f(gamma + vi * 8, gg[c]);
@@ -81,8 +83,16 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
         if (gamma) {
+          if constexpr (kHoist) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = o[e] * gg[c][e] + bb[c][e];
+            for (int e = 0; e < 8; ++e) o[e] = o[e] * gg[c][e] + bb[c][e];
+          } else {
+            float g8[8], b8[8];
+            load8f(gamma + vi * 8, g8);
+            load8f(beta + vi * 8, b8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = o[e] * g8[e] + b8[e];
+          }
         }
         Vec8<T>::store(yr + vi * 8, o);
       }

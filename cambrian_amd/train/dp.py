@@ -108,6 +108,15 @@ class GradSync:
                 b.flat.div_(self.world)
             b.pending = len(b.params)
 
+    def reset(self) -> None:
+        """Forget a step that was abandoned between backward() and finish() (an exception, an out-of-memory probe): wait
+        for collectives already launched and re-arm every bucket's countdown."""
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+            b.pending = len(b.params)
+
     def remove(self) -> None:
         for h in self._handles:
             h.remove()

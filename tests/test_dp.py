@@ -78,6 +78,26 @@ def test_gradsync_single_process_is_identity():
         assert torch.equal(a.grad, b.grad)
 
 
+def test_gradsync_reset_after_an_abandoned_step():
+    """A backward that is not followed by finish() (bench.py's out-of-memory probe, an exception) leaves bucket countdowns
+    part-way: reset() re-arms them, and the next step is the plain one."""
+    from cambrian_amd.train.dp import GradSync
+    m = _model()
+    sync = GradSync(list(m.parameters()), bucket_mb=0.0001)     # one bucket per parameter
+    x = torch.randn(4, 16)
+    (m(x).sum() * 7.0).backward()                               # abandoned: no finish()
+    for p in m.parameters():
+        p.grad = None
+    sync.reset()
+    assert all(b.pending == len(b.params) and b.work is None for b in sync.buckets)
+    m(x).sum().backward()
+    sync.finish()
+    m2 = _model()
+    m2(x).sum().backward()
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a.grad, b.grad)
+
+
 def _worker_sampler(rank, world, port, q):
     """The whole N > 1 recipe on CPU: LengthGroupedSampler order -> rank_batches cut -> per-rank step -> GradSync.  The
     averaged gradient must equal the single-process gradient of the mean loss over the whole megabatch."""
