@@ -26,8 +26,15 @@ constexpr int gemm_smem_bytes() {
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p_in) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  GemmParams p = p_in;
+  if (p.batch > 1) {  // batched launch: problem blockIdx.z of p.batch (operand / result bases advance by the batch strides)
+    const int64_t bz = blockIdx.z;
+    p.A += bz * p.a_bs * (int64_t)sizeof(T);
+    p.B += bz * p.b_bs * (int64_t)sizeof(T);
+    p.C += bz * p.c_bs * (int64_t)(p.out_f32 ? 4 : sizeof(typename Mfma<T>::out_t));
+  }
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
   constexpr int BK = 128 / (int)sizeof(T);
@@ -220,7 +227,7 @@ int launch_gemm(GemmParams& p, int splits, hipStream_t s) {
   }
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits);
+  dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)(p.batch > 1 ? p.batch : 1));
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, p);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
@@ -382,7 +389,14 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   p.slabs = nullptr;
   p.k_per_split = p.K;
   p.a_scale = nullptr; p.b_scale = nullptr;
+  p.batch = d->batch > 1 ? d->batch : 1;
+  p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
   int splits = d->split_k > 1 ? d->split_k : 1;
+  if (p.batch > 1) {
+    // batched problems: plain epilogue (alpha / activation / out dtype), no split-K, 16-byte aligned strides
+    if (splits > 1 || d->bias || d->colscale || d->residual || d->pre_out || sizeof(T) == 1) return CMB_ERR_BAD_ARG;
+    if ((p.a_bs * (int64_t)sizeof(T)) % 16 || (p.b_bs * (int64_t)sizeof(T)) % 16 || (p.c_bs * 2) % 16) return CMB_ERR_ALIGNMENT;
+  }
   if constexpr (sizeof(T) == 1) {
     if (splits > 1) return CMB_ERR_BAD_ARG;
     p.a_scale = d->a_scale; p.b_scale = d->b_scale;
@@ -409,8 +423,10 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   int rc;
   if constexpr (sizeof(T) == 2) {
     int sched = 0;
-    const int m1 = tail_split_rows(p, splits, d->tile_hint);
-    if (m1) {
+    const int m1 = p.batch > 1 ? 0 : tail_split_rows(p, splits, d->tile_hint);
+    if (p.batch > 1) {
+      g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, 1, s);
+    } else if (m1) {
       GemmParams head = p, tail = p;
       head.M = m1;
       tail.M = p.M - m1;

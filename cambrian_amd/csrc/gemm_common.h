@@ -24,6 +24,8 @@ struct GemmParams {
   float* slabs;
   const float* a_scale;  // fp8 operands: per-row dequantisation factors (nullptr otherwise)
   const float* b_scale;
+  int batch;                 // > 1: blockIdx.z walks independent problems of the same shape (128 x 128 kernel only)
+  int64_t a_bs, b_bs, c_bs;  // element strides of A / B / C between consecutive problems of a batch
 };
 
 // storage tag of an OCP e4m3fn operand byte (gfx950 native fp8)

@@ -24,7 +24,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
-ABI_VERSION = 3   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
+ABI_VERSION = 4   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
           -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("tile_hint", C.c_int32),
         ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
+        ("batch", C.c_int32), ("a_batch_stride", C.c_int64), ("b_batch_stride", C.c_int64), ("c_batch_stride", C.c_int64),
     ]
 
 
@@ -69,6 +70,30 @@ class SvaDesc(C.Structure):
         ("dout", C.c_void_p), ("lddo", C.c_int64),
         ("dq", C.c_void_p), ("lddq", C.c_int64),
         ("dkv", C.c_void_p * SVA_MAX_TOWERS),
+    ]
+
+
+class SvaAbsDesc(C.Structure):
+    """cmb_sva_abs_desc (include/cambrian_amd.h): SVA attention with one windowed tower's K / V projections absorbed."""
+    _fields_ = [
+        ("B", C.c_int32), ("qside", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
+        ("ntowers", C.c_int32), ("window_major", C.c_int32),
+        ("r", C.c_int32 * SVA_MAX_TOWERS),
+        ("q", C.c_void_p), ("ldq", C.c_int64),
+        ("kv", C.c_void_p * SVA_MAX_TOWERS), ("ldkv", C.c_int64 * SVA_MAX_TOWERS),
+        ("mask", C.c_void_p * SVA_MAX_TOWERS),
+        ("ra", C.c_int32),
+        ("xhat", C.c_void_p), ("ldx", C.c_int64),
+        ("mask_a", C.c_void_p),
+        ("U", C.c_void_p), ("cb", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("xbar", C.c_void_p), ("m3", C.c_void_p), ("P", C.c_void_p),
+        ("dout", C.c_void_p), ("lddo", C.c_int64),
+        ("dxbar", C.c_void_p), ("dm3", C.c_void_p),
+        ("dq", C.c_void_p), ("lddq", C.c_int64),
+        ("dkv", C.c_void_p * SVA_MAX_TOWERS),
+        ("dU", C.c_void_p), ("dcb", C.c_void_p),
+        ("dxhat", C.c_void_p), ("lddx", C.c_int64),
     ]
 
 
@@ -109,6 +134,8 @@ SIGNATURES = {
     "cmb_rope_apply": (C.c_int, [C.c_int, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p]),
     "cmb_sva_attn_fwd": (C.c_int, [C.POINTER(SvaDesc), _p]),
     "cmb_sva_attn_bwd": (C.c_int, [C.POINTER(SvaDesc), _p]),
+    "cmb_sva_abs_fwd": (C.c_int, [C.POINTER(SvaAbsDesc), _p]),
+    "cmb_sva_abs_bwd": (C.c_int, [C.POINTER(SvaAbsDesc), _p]),
     "cmb_embed_splice_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i32, _p, _p, _p, _p]),
     "cmb_embed_splice_bwd": (C.c_int, [C.c_int, _p, _p, _i64, _i64, _i64, _i32, _p, _p, _p]),
     "cmb_sva_fold_kv_fwd": (C.c_int, [_p] * 6 + [_i64, _i64, _p, _p, _p]),

@@ -789,6 +789,208 @@ def sva_attention(q, kvs: Sequence[torch.Tensor], masks, r_list, B, qside, heads
 
 
 # ================================================================================================
+# absorbed K / V projections of the windowed tower (csrc/sva_absorbed.hip; DESIGN.md §4 "Absorbed K/V")
+# ================================================================================================
+def k_gemm_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch: int, M: int, N: int, K: int, lda: int,
+                   ldb: int, ldc: int, a_bs: int, b_bs: int, c_bs: int) -> torch.Tensor:
+    """``batch`` independent C_z[M,N] = A_z[M,K] @ B_z[N,K]^T in one launch (cmb_gemm, 128 x 128 tile): problem z reads
+    A + z*a_bs (row stride lda), B + z*b_bs (row stride ldb) and writes C + z*c_bs (row stride ldc), all in elements of
+    the tensors' dtype (``out`` may be fp32 for bf16 operands).  The per-head GEMMs of the absorbed SVA projections."""
+    L.require_gpu(a, w, out)
+    if a.dtype != w.dtype:
+        raise L.CambrianAmdError("batched gemm operand dtypes differ")
+    d = GemmDesc()
+    d.dtype, d.out_dtype = L.dtype_code(a.dtype), L.dtype_code(out.dtype)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.a_map = a.data_ptr(), L.identity_map(lda)
+    d.B, d.ldb = w.data_ptr(), ldb
+    d.C, d.c_map = out.data_ptr(), L.identity_map(ldc)
+    d.bias = d.colscale = d.residual = d.pre_out = None
+    d.r_map = d.p_map = L.identity_map(0)
+    d.act, d.alpha, d.beta, d.split_k, d.tile_hint = L.ACT_NONE, 1.0, 0.0, 1, 0
+    d.workspace, d.workspace_bytes = None, 0
+    d.batch, d.a_batch_stride, d.b_batch_stride, d.c_batch_stride = batch, a_bs, b_bs, c_bs
+    rc = L.load().cmb_gemm(C.byref(d), L.stream_ptr(a.device))
+    L.check(rc, f"cmb_gemm(batch={batch}, M={M}, N={N}, K={K})")
+    return out
+
+
+class HeadExpandFn(torch.autograd.Function):
+    """U[q, h, :] = x[q, h*hd:(h+1)*hd] @ W[h*hd:(h+1)*hd, :]   (x [Bq, H*hd], W [H*hd, Cin] -> U [Bq, H, Cin]): the K
+    projection of the windowed tower applied to the QUERY (U = W_k,h^T q_h) and, with x = d(o), the V projection's backward
+    (d Xb = W_v,h^T d o_h).  H GEMMs with K = hd = 64 in one batched launch; backward: dx_h = dU_h W_h^T (N = 64),
+    dW_h = x_h^T dU_h (M = 64, contraction over the queries: both operands transposed first)."""
+
+    @staticmethod
+    def forward(ctx, x, w, heads: int):
+        Bq, C = x.shape
+        hd, Cin = C // heads, w.shape[1]
+        w_c = k_cast(w, x.dtype)
+        w_t = k_transpose(w_c, C)                                    # [Cin, C]: rows c, the head's 64 inputs contiguous
+        U = torch.empty((Bq, heads, Cin), dtype=x.dtype, device=x.device)
+        xc = x if x.is_contiguous() else x.contiguous()
+        k_gemm_batched(xc, w_t, U, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=C, ldc=heads * Cin, a_bs=hd, b_bs=hd, c_bs=Cin)
+        ctx.save_for_backward(xc, w_c)
+        ctx.heads, ctx.w_dtype = heads, w.dtype
+        return U
+
+    @staticmethod
+    def backward(ctx, dU):
+        x, w_c = ctx.saved_tensors
+        heads = ctx.heads
+        Bq, C = x.shape
+        hd, Cin = C // heads, w_c.shape[1]
+        dU = _as_dtype_contig(dU, x.dtype)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((Bq, C), dtype=x.dtype, device=x.device)
+            k_gemm_batched(dU, w_c, dx, batch=heads, M=Bq, N=hd, K=Cin, lda=heads * Cin, ldb=Cin, ldc=C, a_bs=Cin,
+                           b_bs=hd * Cin, c_bs=hd)
+        if ctx.needs_input_grad[1]:
+            bqp = pad_to(Bq, 64)
+            x_t = k_transpose(x, bqp)                                # [C, Bqp]
+            du_t = k_transpose(dU.view(Bq, heads * Cin), bqp)        # [H*Cin, Bqp]
+            dw = torch.empty((C, Cin), dtype=torch.float32, device=x.device)
+            k_gemm_batched(x_t, du_t, dw, batch=heads, M=hd, N=Cin, K=bqp, lda=bqp, ldb=bqp, ldc=Cin, a_bs=hd * bqp,
+                           b_bs=Cin * bqp, c_bs=hd * Cin)
+            if ctx.w_dtype != torch.float32:
+                dw = dw.to(ctx.w_dtype)
+        return dx, dw, None
+
+
+class HeadContractFn(torch.autograd.Function):
+    """y[q, h*hd + j] = Xb[q, h, :] . W[h*hd + j, :]   (Xb [Bq, H, Cin], W [H*hd, Cin] -> y [Bq, H*hd]): the V projection of
+    the windowed tower applied to the attention-weighted token mix (o_h = W_v,h Xb_h).  H GEMMs with N = hd = 64 in one
+    batched launch; backward: dXb_h = dy_h W_h (K = 64), dW_h = dy_h^T Xb_h."""
+
+    @staticmethod
+    def forward(ctx, xb, w, heads: int):
+        Bq, H, Cin = xb.shape
+        C = w.shape[0]
+        hd = C // heads
+        w_c = k_cast(w, xb.dtype)
+        xbc = xb if xb.is_contiguous() else xb.contiguous()
+        y = torch.empty((Bq, C), dtype=xb.dtype, device=xb.device)
+        k_gemm_batched(xbc, w_c, y, batch=heads, M=Bq, N=hd, K=Cin, lda=heads * Cin, ldb=Cin, ldc=C, a_bs=Cin,
+                       b_bs=hd * Cin, c_bs=hd)
+        ctx.save_for_backward(xbc, w_c)
+        ctx.heads, ctx.w_dtype = heads, w.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w_c = ctx.saved_tensors
+        heads = ctx.heads
+        Bq, H, Cin = xb.shape
+        C = w_c.shape[0]
+        hd = C // heads
+        dy = _as_dtype_contig(dy, xb.dtype)
+        dxb = dw = None
+        if ctx.needs_input_grad[0]:
+            w_t = k_transpose(w_c, C)                                # [Cin, C]
+            dxb = torch.empty((Bq, heads, Cin), dtype=xb.dtype, device=xb.device)
+            k_gemm_batched(dy, w_t, dxb, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=C, ldc=heads * Cin, a_bs=hd, b_bs=hd,
+                           c_bs=Cin)
+        if ctx.needs_input_grad[1]:
+            bqp = pad_to(Bq, 64)
+            dy_t = k_transpose(dy, bqp)                              # [C, Bqp]
+            xb_t = k_transpose(xb.view(Bq, heads * Cin), bqp)        # [H*Cin, Bqp]
+            dw = torch.empty((C, Cin), dtype=torch.float32, device=xb.device)
+            k_gemm_batched(dy_t, xb_t, dw, batch=heads, M=hd, N=Cin, K=bqp, lda=bqp, ldb=bqp, ldc=Cin, a_bs=hd * bqp,
+                           b_bs=Cin * bqp, c_bs=hd * Cin)
+            if ctx.w_dtype != torch.float32:
+                dw = dw.to(ctx.w_dtype)
+        return dxb, dw, None
+
+
+def _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, U, cb, B, qside, window_major):
+    d.B, d.qside, d.heads, d.hd = B, qside, 16, 64
+    d.ntowers, d.window_major, d.ra = len(kvs), 1 if window_major else 0, ra
+    d.q, d.ldq = q.data_ptr(), q.stride(0)
+    for i, kv in enumerate(kvs):
+        d.r[i] = 1
+        d.kv[i], d.ldkv[i] = kv.data_ptr(), kv.stride(0)
+        d.mask[i] = None if masks[i] is None else masks[i].data_ptr()
+    d.xhat, d.ldx = xhat.data_ptr(), xhat.stride(0)
+    d.mask_a = None if mask_a is None else mask_a.data_ptr()
+    d.U, d.cb = U.data_ptr(), cb.data_ptr()
+
+
+class SvaAbsorbedFn(torch.autograd.Function):
+    """cmb_sva_abs_fwd / _bwd: per query the joint softmax over the one-key towers' projected K|V rows and the windowed
+    tower's tokens (scored against U), returning (direct towers' part of the output [Bq, 1024], Xb [Bq, 16, 1024], m3 [Bq, 16])."""
+
+    @staticmethod
+    def forward(ctx, q, U, cb, xhat, B: int, qside: int, ra: int, masks, mask_a, window_major: bool, *kvs):
+        L.require_gpu(q, U, cb, xhat, *kvs)
+        Bq = B * qside * qside
+        if q.dtype != torch.bfloat16 or tuple(q.shape) != (Bq, 1024) or tuple(U.shape) != (Bq, 16, 1024):
+            raise L.CambrianAmdError("absorbed SVA attention: bf16, 16 heads x 64, 1024-wide features")
+        if xhat.shape[0] != B * (qside * ra) ** 2 or xhat.shape[1] != 1024 or xhat.stride(1) != 1:
+            raise L.CambrianAmdError("absorbed SVA attention: xhat must be [B*(qside*ra)^2, 1024]")
+        kvs = [kv if kv.stride(1) == 1 else kv.contiguous() for kv in kvs]
+        Uc, cbc = U.contiguous(), cb.to(torch.float32).contiguous()
+        nkeys = len(kvs) + ra * ra
+        out = torch.empty((Bq, 1024), dtype=q.dtype, device=q.device)
+        xbar = torch.empty((Bq, 16, 1024), dtype=q.dtype, device=q.device)
+        m3 = torch.empty((Bq, 16), dtype=torch.float32, device=q.device)
+        P = torch.empty((Bq, 16, nkeys), dtype=torch.float32, device=q.device)
+        d = L.SvaAbsDesc()
+        _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, Uc, cbc, B, qside, window_major)
+        d.out, d.ldo, d.xbar, d.m3, d.P = out.data_ptr(), out.stride(0), xbar.data_ptr(), m3.data_ptr(), P.data_ptr()
+        L.check(L.load().cmb_sva_abs_fwd(C.byref(d), L.stream_ptr(q.device)), "cmb_sva_abs_fwd")
+        ctx.cfg = (B, qside, ra, window_major)
+        ctx.masks, ctx.mask_a = masks, mask_a
+        ctx.cb_dtype = cb.dtype
+        ctx.save_for_backward(q, Uc, cbc, xhat, P, *kvs)
+        return out, xbar, m3
+
+    @staticmethod
+    def backward(ctx, dout, dxbar, dm3):
+        q, U, cb, xhat, P, *kvs = ctx.saved_tensors
+        B, qside, ra, window_major = ctx.cfg
+        Bq = q.shape[0]
+        dev = q.device
+        dout = torch.zeros_like(q) if dout is None else _as_dtype_contig(dout, q.dtype)
+        dxbar = torch.zeros_like(U) if dxbar is None else _as_dtype_contig(dxbar, q.dtype)
+        dm3 = torch.zeros((Bq, 16), dtype=torch.float32, device=dev) if dm3 is None else dm3.to(torch.float32).contiguous()
+        dq = torch.empty_like(q)
+        dkvs = [torch.empty_like(kv) for kv in kvs]
+        dU = torch.empty_like(U)
+        dcb = torch.empty((Bq, 16), dtype=torch.float32, device=dev)
+        dxhat = torch.empty((xhat.shape[0], 1024), dtype=q.dtype, device=dev)
+        d = L.SvaAbsDesc()
+        _fill_sva_abs(d, q, kvs, ctx.masks, xhat, ctx.mask_a, ra, U, cb, B, qside, window_major)
+        # (the forward outputs are not read by the backward kernel, but the descriptor's forward fields must be set)
+        d.out, d.ldo, d.xbar, d.m3, d.P = dq.data_ptr(), dq.stride(0), dU.data_ptr(), dcb.data_ptr(), P.data_ptr()
+        d.dout, d.lddo, d.dxbar, d.dm3 = dout.data_ptr(), dout.stride(0), dxbar.data_ptr(), dm3.data_ptr()
+        d.dq, d.lddq = dq.data_ptr(), dq.stride(0)
+        for i, t in enumerate(dkvs):
+            d.dkv[i] = t.data_ptr()
+        d.dU, d.dcb, d.dxhat, d.lddx = dU.data_ptr(), dcb.data_ptr(), dxhat.data_ptr(), dxhat.stride(0)
+        L.check(L.load().cmb_sva_abs_bwd(C.byref(d), L.stream_ptr(dev)), "cmb_sva_abs_bwd")
+        if ctx.cb_dtype != torch.float32:
+            dcb = dcb.to(ctx.cb_dtype)
+        return (dq, dU, dcb, dxhat, None, None, None, None, None, None, *dkvs)
+
+
+def sva_absorbed_attention(qh, kvs_direct, masks_direct, xhat, mask_a, ra: int, wk, bk, wv, bv, B: int, qside: int,
+                           window_major: bool = False) -> torch.Tensor:
+    """The SVA attention core with the windowed tower's K / V projections absorbed (csrc/sva_absorbed.hip): ``qh`` [Bq, 1024]
+    projected queries; ``kvs_direct`` K|V rows [Bq, 2048] of the one-key towers with their uint8 masks [Bq] (or None);
+    ``xhat`` the windowed tower's normalised tokens; (wk, bk, wv, bv) its folded projection [1024, 1024] / [1024] (fp32,
+    autograd-tracked).  Returns the attention output [Bq, 1024] (before o_proj), identical to ``sva_attention`` on the K|V
+    rows ``xhat @ [wk; wv]^T + [bk; bv]``."""
+    Bq = qh.shape[0]
+    U = HeadExpandFn.apply(qh, wk, 16)                                           # [Bq, 16, 1024]
+    cb = (qh.view(Bq, 16, 64).float() * bk.view(16, 64).float()).sum(-1)        # [Bq, 16]
+    out_d, xbar, m3 = SvaAbsorbedFn.apply(qh, U, cb, xhat, B, qside, ra, list(masks_direct), mask_a, window_major, *kvs_direct)
+    o3 = HeadContractFn.apply(xbar, wv, 16)                                      # [Bq, 1024]
+    ob = (m3[:, :, None] * bv.view(16, 64).float()).reshape(Bq, 1024).to(qh.dtype)
+    return out_d + o3 + ob
+
+
+# ================================================================================================
 # autograd: token mean, embedding splice
 # ================================================================================================
 class TokenMeanFn(torch.autograd.Function):

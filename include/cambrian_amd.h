@@ -57,10 +57,10 @@ typedef struct cmb_rowmap {
 /* library / build identification ("cambrian_amd <version> gfx950"). */
 const char* cmb_version(void);
 /* ABI revision: bumped whenever an entry point's signature or a descriptor's layout changes (round 2's key_valid
- * arguments = 2, round 3's fold_kv workspace = 3).  Bindings must compare it with the revision they
+ * arguments = 2, round 3's fold_kv workspace = 3, the batch fields of cmb_gemm_desc = 4).  Bindings must compare it with the revision they
  * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
  * library still resolves, and a shifted argument list corrupts memory instead of failing. */
-#define CMB_ABI_VERSION 3
+#define CMB_ABI_VERSION 4
 int cmb_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -102,6 +102,11 @@ typedef struct cmb_gemm_desc {
   const float* a_scale;    /* CMB_FP8_E4M3 only: [M] fp32 dequantisation factor of each A row (or NULL = 1) */
   const float* b_scale;    /* CMB_FP8_E4M3 only: [N] fp32 dequantisation factor of each B row (or NULL = 1);
                               the accumulator is multiplied by a_scale[m] * b_scale[n] before alpha / bias */
+  int32_t batch;           /* > 1: `batch` independent problems of this shape in one launch (the sixteen per-head GEMMs of
+                              the absorbed SVA projections, vision_sampler.py:187-189 restated per head): problem z uses
+                              A + z * a_batch_stride, B + z * b_batch_stride, C + z * c_batch_stride (elements; 16-byte
+                              multiples).  bf16 / fp32, 128x128 tile, no bias / colscale / residual / pre_out / split-K */
+  int64_t a_batch_stride, b_batch_stride, c_batch_stride;
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);
@@ -227,6 +232,53 @@ typedef struct cmb_sva_desc {
 
 int cmb_sva_attn_fwd(const cmb_sva_desc* d, void* stream);
 int cmb_sva_attn_bwd(const cmb_sva_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SVA cross-attention core with ONE windowed tower's K / V projections absorbed into the query side
+ * (same reference lines as above: vision_sampler.py:187-230; bf16, heads = 16, hd = 64, feature width 1024).
+ * Every token of an s x s-window tower is seen by exactly one query, so instead of projecting K and V per token
+ * (kv_i above) the caller supplies, for that tower,
+ *   xhat : [B * (qside*ra)^2, 1024]  the LayerNorm-normalised tokens (affines folded into W_k, W_v, b_k, b_v)
+ *   U    : [Bq, 16, 1024]            U[q,h,:] = W_k,h^T q_h           (cmb_gemm, batch = 16, K = 64)
+ *   cb   : fp32 [Bq, 16]             cb[q,h] = b_k,h . q_h
+ * and receives, besides the joint-softmax probabilities P (fp32 [Bq, 16, ntowers + ra*ra], saved for the backward),
+ *   out  : [Bq, 1024]   sum over the DIRECT towers' keys of p * V           (kv / mask / r as in cmb_sva_desc; r_i == 1)
+ *   xbar : [Bq, 16, 1024]  Xb[q,h,:] = sum_t p[q,h,t] xhat_t     -> the absorbed tower's output is W_v,h Xb + m3 b_v,h
+ *   m3   : fp32 [Bq, 16]   sum_t p[q,h,t] over the absorbed tower's tokens
+ * with score[q,h,t] = (xhat_t . U[q,h,:] + cb[q,h]) / sqrt(hd) for the absorbed tokens and q_h . K_h / sqrt(hd) for the
+ * direct ones.  The backward takes d(out), d(xbar), d(m3) and writes dq (through the direct towers only), dkv of the direct
+ * towers, dU, d(cb) and d(xhat) (every element exactly once).  Neither K|V nor dK|dV of the absorbed tower exist.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cmb_sva_abs_desc {
+  int32_t B, qside, heads, hd;
+  int32_t ntowers;       /* directly projected towers (may be 0), each with r_i == 1 */
+  int32_t window_major;  /* layout of xhat: 0 tower-token-major, 1 [Bq, ra*ra, 1024] */
+  int32_t r[CMB_SVA_MAX_TOWERS];
+  const void* q;   int64_t ldq;
+  const void* kv[CMB_SVA_MAX_TOWERS]; int64_t ldkv[CMB_SVA_MAX_TOWERS];
+  const uint8_t* mask[CMB_SVA_MAX_TOWERS];
+  int32_t ra;            /* window side of the absorbed tower, ra*ra <= 16 */
+  const void* xhat; int64_t ldx;
+  const uint8_t* mask_a; /* uint8 [Bq, ra*ra] or NULL */
+  const void* U;
+  const float* cb;
+  void* out;       int64_t ldo;
+  void* xbar;
+  float* m3;
+  float* P;
+  /* backward only */
+  const void* dout; int64_t lddo;
+  const void* dxbar;
+  const float* dm3;
+  void* dq;         int64_t lddq;
+  void* dkv[CMB_SVA_MAX_TOWERS];
+  void* dU;
+  float* dcb;
+  void* dxhat;      int64_t lddx;
+} cmb_sva_abs_desc;
+
+int cmb_sva_abs_fwd(const cmb_sva_abs_desc* d, void* stream);
+int cmb_sva_abs_bwd(const cmb_sva_abs_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Embedding merge (static layout): cambrian_arch.py:413-420 (newline column) + :457-490.

@@ -1,0 +1,71 @@
+"""Test infrastructure (never imported by the product): plain-torch restatements of the SVA attention core in its DIRECT form
+(vision_sampler.py:187-230: K and V projected per token) and in the ABSORBED form of cambrian_amd/csrc/sva_absorbed.hip (the
+windowed tower's projections applied on the query side).  Window-major inputs, any dtype / device; autograd gives the
+reference gradients.  tests/test_absorbed_math.py shows the two forms agree (CPU, fp32); tests/test_sva_absorbed_gpu.py
+compares the HIP kernels with ``absorbed``."""
+import math
+
+import torch
+
+
+def _acc(t):
+    """fp32 arithmetic for bf16 / fp32 inputs (what the kernels do), fp64 when the test feeds fp64."""
+    return t.double() if t.dtype == torch.float64 else t.float()
+
+
+def direct(qh, kv_small, masks_small, xhat, mask_a, wk, bk, wv, bv, heads=16):
+    """qh [Bq, C]; kv_small[i] [Bq, 2C] (K|V rows of the one-key towers); masks_small[i] bool [Bq] or None; xhat [Bq, T, Cin]
+    (the windowed tower's normalised tokens, window-major); mask_a bool [Bq, T] or None; wk, wv [C, Cin]; bk, bv [C]."""
+    Bq, C = qh.shape
+    hd = C // heads
+    k3 = xhat @ wk.T + bk          # [Bq, T, C]
+    v3 = xhat @ wv.T + bv
+    ks = [kv[:, None, :C] for kv in kv_small] + [k3]
+    vs = [kv[:, None, C:] for kv in kv_small] + [v3]
+    k = torch.cat(ks, 1).view(Bq, -1, heads, hd).transpose(1, 2)     # [Bq, H, nk, hd]
+    v = torch.cat(vs, 1).view(Bq, -1, heads, hd).transpose(1, 2)
+    q = qh.view(Bq, heads, 1, hd)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)                     # [Bq, H, 1, nk]
+    T = xhat.shape[1]
+    m = [torch.ones(Bq, 1, dtype=torch.bool, device=qh.device) if mm is None else mm.view(Bq, 1) for mm in masks_small]
+    m.append(torch.ones(Bq, T, dtype=torch.bool, device=qh.device) if mask_a is None else mask_a)
+    mask = torch.cat(m, 1)[:, None, None, :]
+    s = s.masked_fill(~mask, float("-inf"))
+    p = torch.softmax(_acc(s), -1).to(v.dtype)
+    return (p @ v).transpose(1, 2).reshape(Bq, C)
+
+
+def absorbed_parts(qh, kv_small, masks_small, xhat, mask_a, U, cb, heads=16):
+    """The part cmb_sva_abs_fwd computes: (out_direct [Bq, C], xbar [Bq, H, Cin], m3 [Bq, H], P [Bq, H, nkeys])."""
+    Bq, C = qh.shape
+    hd = C // heads
+    scale = 1.0 / math.sqrt(hd)
+    q = qh.view(Bq, heads, hd)
+    s_small = [(_acc(q) * _acc(kv[:, :C].view(Bq, heads, hd))).sum(-1) * scale for kv in kv_small]          # each [Bq, H]
+    s_a = (torch.einsum("qtc,qhc->qht", _acc(xhat), _acc(U)) + _acc(cb)[:, :, None]) * scale    # [Bq, H, T]
+    s = torch.cat([_acc(x)[:, :, None] for x in s_small] + [s_a], -1)
+    T = xhat.shape[1]
+    m = [torch.ones(Bq, 1, dtype=torch.bool, device=qh.device) if mm is None else mm.view(Bq, 1) for mm in masks_small]
+    m.append(torch.ones(Bq, T, dtype=torch.bool, device=qh.device) if mask_a is None else mask_a)
+    s = s.masked_fill(~torch.cat(m, 1)[:, None, :], float("-inf"))
+    P = torch.softmax(s, -1)                                                                   # fp32 [Bq, H, nkeys]
+    nd = len(kv_small)
+    out = torch.zeros(Bq, heads, hd, dtype=P.dtype, device=qh.device)
+    for i, kv in enumerate(kv_small):
+        out = out + P[:, :, i, None] * _acc(kv[:, C:].view(Bq, heads, hd))
+    pa = P[:, :, nd:]
+    xbar = torch.einsum("qht,qtc->qhc", pa, _acc(xhat))
+    return out.reshape(Bq, C), xbar, pa.sum(-1), P
+
+
+def absorbed(qh, kv_small, masks_small, xhat, mask_a, wk, bk, wv, bv, heads=16):
+    """The whole absorbed form, composed as cambrian_amd/model/vision_sampler.py composes it."""
+    Bq, C = qh.shape
+    hd = C // heads
+    Cin = xhat.shape[-1]
+    q = _acc(qh.view(Bq, heads, hd))
+    U = torch.einsum("qhj,hjc->qhc", q, _acc(wk.view(heads, hd, Cin)))
+    cb = (q * _acc(bk.view(heads, hd))).sum(-1)
+    out, xbar, m3, _ = absorbed_parts(qh, kv_small, masks_small, xhat, mask_a, U, cb, heads)
+    o3 = torch.einsum("qhc,hjc->qhj", xbar, _acc(wv.view(heads, hd, Cin))) + m3[:, :, None] * _acc(bv.view(heads, hd))
+    return out + o3.reshape(Bq, C)

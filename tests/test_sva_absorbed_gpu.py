@@ -1,0 +1,150 @@
+"""`-m gpu`: the absorbed form of the SVA attention core (csrc/sva_absorbed.hip + the batched per-head GEMMs of cmb_gemm)
+against plain-torch restatements (tests/absorbed_ref.py; tests/test_absorbed_math.py shows on the CPU that the absorbed and
+the direct restatement are the same function).  bf16 operands, fp32 references on the same rounded values."""
+import pytest
+import torch
+
+from conftest import fit_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from cambrian_amd import lib as L
+    from cambrian_amd import ops
+    return ops, L
+
+
+def test_batched_head_gemms_match_einsum(dev):
+    """cmb_gemm `batch`: the two per-head projections and their gradients (K = 64, N = 64 and M = 64 problems)."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(1)
+    Bq, H, hd, Cin = 1000, 16, 64, 1024
+    dt = torch.bfloat16
+    x = torch.randn(Bq, H * hd, generator=g).to(dt).to(dev).requires_grad_()
+    w = (torch.randn(H * hd, Cin, generator=g) * 0.05).to(dev).requires_grad_()          # fp32 master
+    U = ops.HeadExpandFn.apply(x, w, H)
+    wr = w.detach().to(dt).float()
+    ref = torch.einsum("qhj,hjc->qhc", x.detach().float().view(Bq, H, hd), wr.view(H, hd, Cin))
+    assert U.shape == (Bq, H, Cin) and rel_err(U, ref) < 1e-2
+    gU = torch.randn(Bq, H, Cin, generator=g).to(dt).to(dev)
+    U.backward(gU)
+    dx_ref = torch.einsum("qhc,hjc->qhj", gU.float(), wr.view(H, hd, Cin)).reshape(Bq, H * hd)
+    dw_ref = torch.einsum("qhj,qhc->hjc", x.detach().float().view(Bq, H, hd), gU.float()).reshape(H * hd, Cin)
+    assert rel_err(x.grad, dx_ref) < 1e-2 and rel_err(w.grad, dw_ref) < 1e-2 and w.grad.dtype == torch.float32
+    xb = torch.randn(Bq, H, Cin, generator=g).to(dt).to(dev).requires_grad_()
+    w2 = (torch.randn(H * hd, Cin, generator=g) * 0.05).to(dev).requires_grad_()
+    y = ops.HeadContractFn.apply(xb, w2, H)
+    w2r = w2.detach().to(dt).float()
+    yref = torch.einsum("qhc,hjc->qhj", xb.detach().float(), w2r.view(H, hd, Cin)).reshape(Bq, H * hd)
+    assert rel_err(y, yref) < 1e-2
+    gy = torch.randn(Bq, H * hd, generator=g).to(dt).to(dev)
+    y.backward(gy)
+    assert rel_err(xb.grad, torch.einsum("qhj,hjc->qhc", gy.float().view(Bq, H, hd), w2r.view(H, hd, Cin))) < 1e-2
+    assert rel_err(w2.grad, torch.einsum("qhj,qhc->hjc", gy.float().view(Bq, H, hd), xb.detach().float()).reshape(H * hd, Cin)) < 1e-2
+
+
+def _case(dev, B, qside, ra, nsmall, window_major, seed):
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.bfloat16
+    C = 1024
+    Bq, T = B * qside * qside, ra * ra
+    def rn(*s, scale=1.0):
+        return (torch.randn(*s, generator=g) * scale).to(dt).to(dev)
+    qh = rn(Bq, C)
+    kvs = [rn(Bq, 2 * C) for _ in range(nsmall)]
+    xh_win = rn(Bq, T, C)                                  # window-major truth
+    if window_major:
+        xhat = xh_win.reshape(Bq * T, C).clone()
+    else:                                                  # tower-token-major: token (b, qy*ra+ry, qx*ra+rx)
+        xhat = xh_win.view(B, qside, qside, ra, ra, C).permute(0, 1, 3, 2, 4, 5).reshape(B * (qside * ra) ** 2, C).contiguous()
+    masks = [None] + [(torch.rand(Bq, generator=g) > 0.2).to(torch.uint8).to(dev) for _ in range(nsmall - 1)] if nsmall else []
+    mask_a = (torch.rand(Bq, T, generator=g) > 0.3).to(torch.uint8)
+    mask_a[:, 0] = 1
+    mask_a = mask_a.to(dev)
+    wk, wv = (torch.randn(C, C, generator=g) * 0.03).to(dev), (torch.randn(C, C, generator=g) * 0.03).to(dev)
+    bk, bv = (torch.randn(C, generator=g) * 0.5).to(dev), (torch.randn(C, generator=g) * 0.5).to(dev)
+    return dict(qh=qh, kvs=kvs, xh_win=xh_win, xhat=xhat, masks=masks, mask_a=mask_a, wk=wk, bk=bk, wv=wv, bv=bv, Bq=Bq, T=T)
+
+
+@pytest.mark.parametrize("B,qside,ra,nsmall,window_major", [(2, 3, 4, 3, False), (1, 5, 4, 3, True), (2, 4, 2, 1, False),
+                                                          (3, 2, 4, 0, False), (1, 24, 4, 3, False)])
+def test_absorbed_attention_matches_direct_reference(dev, B, qside, ra, nsmall, window_major):
+    """Forward and every gradient of ops.sva_absorbed_attention against the DIRECT reference (K and V projected per token,
+    fp32, autograd) on the same bf16-rounded operands; masks on both kinds of key; both token layouts."""
+    ops, L = _ops()
+    from absorbed_ref import direct
+    c = _case(dev, B, qside, ra, nsmall, window_major, 17 + B + qside + ra)
+    leaves_hip = dict(qh=c["qh"].clone().requires_grad_(), xhat=c["xhat"].clone().requires_grad_(),
+                      wk=c["wk"].clone().requires_grad_(), bk=c["bk"].clone().requires_grad_(),
+                      wv=c["wv"].clone().requires_grad_(), bv=c["bv"].clone().requires_grad_())
+    kv_hip = [k.clone().requires_grad_() for k in c["kvs"]]
+    out = ops.sva_absorbed_attention(leaves_hip["qh"], kv_hip, c["masks"], leaves_hip["xhat"], c["mask_a"], ra,
+                                     leaves_hip["wk"], leaves_hip["bk"], leaves_hip["wv"], leaves_hip["bv"], B, qside,
+                                     window_major=window_major)
+    w = torch.randn(c["Bq"], 1024, generator=torch.Generator().manual_seed(5)).to(dev)
+    (out.float() * w).sum().backward()
+    # reference: fp32 on the bf16-rounded activations and bf16-rounded weights (the kernels cast the fp32 masters)
+    r = dict(qh=c["qh"].float().requires_grad_(), xh=c["xh_win"].float().requires_grad_(),
+             wk=c["wk"].to(torch.bfloat16).float().requires_grad_(), bk=c["bk"].clone().requires_grad_(),
+             wv=c["wv"].to(torch.bfloat16).float().requires_grad_(), bv=c["bv"].clone().requires_grad_())
+    kv_ref = [k.float().requires_grad_() for k in c["kvs"]]
+    mref = [None if m is None else m.bool() for m in c["masks"]]
+    ref = direct(r["qh"], kv_ref, mref, r["xh"], c["mask_a"].bool(), r["wk"], r["bk"], r["wv"], r["bv"])
+    (ref * w).sum().backward()
+    assert rel_err(out, ref.detach()) < 1.5e-2, rel_err(out, ref.detach())
+    assert fit_err(out, ref.detach())[0] < 5e-3
+    T, Bq = c["T"], c["Bq"]
+    if window_major:
+        dxh = leaves_hip["xhat"].grad.view(Bq, T, 1024)
+    else:
+        dxh = leaves_hip["xhat"].grad.view(B, qside, ra, qside, ra, 1024).permute(0, 1, 3, 2, 4, 5).reshape(Bq, T, 1024)
+    checks = [("qh", leaves_hip["qh"].grad, r["qh"].grad), ("xhat", dxh, r["xh"].grad), ("wk", leaves_hip["wk"].grad, r["wk"].grad),
+              ("bk", leaves_hip["bk"].grad, r["bk"].grad), ("wv", leaves_hip["wv"].grad, r["wv"].grad),
+              ("bv", leaves_hip["bv"].grad, r["bv"].grad)]
+    checks += [(f"kv{i}", a.grad, b.grad) for i, (a, b) in enumerate(zip(kv_hip, kv_ref))]
+    for name, a, b in checks:
+        assert a is not None and b is not None, name
+        e = rel_err(a, b)
+        assert e < 3e-2, (name, e)
+    # masked tokens of the windowed tower: exactly zero gradient rows
+    dead = ~c["mask_a"].bool()
+    assert torch.count_nonzero(dxh[dead]) == 0
+
+
+def test_absorbed_path_is_what_the_layer_runs(dev, monkeypatch):
+    """VisionCrossAttentionLayer takes the absorbed path for the release tower set in bf16 and gives the per-token path's
+    result (CAMBRIAN_AMD_ABSORB_KV=0) within bf16 rounding, forward and parameter gradients."""
+    from cambrian_amd import ops
+    import cambrian_amd.model.vision_sampler as VS
+    torch.manual_seed(0)
+    m = VS.VisionTokenSampler(1024, 1024, [1024] * 4, [1, 1, 1, 4], 1024, 1).to(dev)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "pos_embed" in n:
+                p.mul_(0.3)
+    B, qside = 2, 6
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(B * qside * qside, 1024, generator=g).to(dev, torch.bfloat16)
+    ctx = torch.randn(B, 1024, generator=g).to(dev, torch.bfloat16)
+    feats = [torch.randn(B * (qside * s) ** 2, 1024, generator=g).to(dev, torch.bfloat16) for s in (1, 1, 1, 4)]
+    masks = [None, None, None, (torch.rand(B * qside * qside, 16, generator=g) > 0.25).to(torch.uint8).to(dev)]
+    masks[3][:, 5] = 1
+    outs, grads = [], []
+    calls = []
+    real = ops.sva_absorbed_attention
+    monkeypatch.setattr(ops, "sva_absorbed_attention", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    for on in (True, False):
+        monkeypatch.setattr(VS, "ABSORB_KV", on)
+        m.zero_grad(set_to_none=True)
+        holders = [ops.GradAccumulator() for _ in range(4)]
+        fd = [f.clone().requires_grad_() for f in feats]
+        shared = [ops.shared_grad(f, h) for f, h in zip(fd, holders)]
+        out = m.forward_fused(q, ctx, shared, masks, holders, B, qside)
+        out.float().pow(2).mean().backward()
+        outs.append(out.detach().float())
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters()} | {f"feat{i}": f.grad.clone() for i, f in enumerate(fd)})
+    assert len(calls) == 1                                   # the absorbed path ran exactly when it was on
+    assert rel_err(outs[0], outs[1]) < 2e-2
+    for n in grads[0]:
+        assert rel_err(grads[0][n], grads[1][n].float()) < 6e-2, (n, rel_err(grads[0][n], grads[1][n].float()))
