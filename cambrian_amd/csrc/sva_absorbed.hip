@@ -24,9 +24,16 @@
 namespace {
 
 constexpr int kHeads = 16, kHd = 64, kC = 1024, kMaxKeys = 16;
+constexpr int kWinBytes = kMaxKeys * kC * 2;                       // one wave's token window in LDS: 32 KiB
+constexpr int kScratchF32 = 4 * kMaxKeys * kHeads * 4;            // [wave][token][head] fp32: 4 KiB
+constexpr int kScratchPair = 4 * (kMaxKeys / 2) * kHeads * 4;     // [wave][token pair][head] bf16x2: 2 KiB
+constexpr int kSmemFwd = 4 * kWinBytes + kScratchF32 + kScratchPair;                    // + scores, + P pairs
+constexpr int kSmemBwd = 4 * kWinBytes + 2 * kScratchF32 + kScratchF32 + kScratchPair;  // + P, dP, + (P, dS), + dS pairs
 constexpr int kMaxD = 4;  // directly projected towers (one key each) beside the absorbed one
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 struct AbsParams {
   int B, qside, ntowers, window_major;
@@ -55,10 +62,17 @@ struct AbsParams {
   float scale;
 };
 
+// x + (x of the lane `ctrl` names), one v_add_f32_dpp
+template <int CTRL>
+__device__ __forceinline__ float add_dpp(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the 8 lanes of a group (lane ^ 1, lane ^ 2, 7 - lane: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror)
 __device__ __forceinline__ float head_sum8(float v) {
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
+  v = add_dpp<0xB1>(v);
+  v = add_dpp<0x4E>(v);
+  v = add_dpp<0x141>(v);
   return v;
 }
 
@@ -72,36 +86,95 @@ __device__ __forceinline__ float dot8(const bf16x8_t& a, const bf16x8_t& b, floa
   return acc;
 }
 
+// packed-pair arithmetic of the token-mix products.  A sum over tokens (or heads) of coefficient x row-element runs two terms
+// per v_dot2c_f32_bf16: the row elements of two tokens are interleaved into bf16 pairs (v_perm_b32, once per pair of rows)
+// and the two wave-uniform coefficients travel as one bf16 pair read from LDS (broadcast) — no bf16 -> fp32 converts and
+// half the multiply instructions of the fp32 FMA form; the coefficients (probabilities, dS) are rounded to bf16, as the P
+// operand of every MFMA attention kernel is.
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ uint32_t pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }  // {a.lo, b.lo}
+__device__ __forceinline__ uint32_t pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }  // {a.hi, b.hi}
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+// rows a, b (8 bf16 each) -> pr[e] = {a[e], b[e]}
+__device__ __forceinline__ void interleave8(const u32x4_t& a, const u32x4_t& b, uint32_t (&pr)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pr[2 * i] = pair_lo(a[i], b[i]);
+    pr[2 * i + 1] = pair_hi(a[i], b[i]);
+  }
+}
+// acc[h][e] += pr[e] . c[h] for the 16 heads' coefficient pairs at cp (LDS, wave-uniform address)
+__device__ __forceinline__ void mix16(const uint32_t (&pr)[8], const uint32_t* cp, float (&acc)[kHeads][8]) {
+#pragma unroll
+  for (int hq = 0; hq < 4; ++hq) {
+    const u32x4_t c4 = *reinterpret_cast<const u32x4_t*>(cp + hq * 4);
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[hq * 4 + hh][e] = dot2(pr[e], c4[hh], acc[hq * 4 + hh][e]);
+  }
+}
+
+// the halving exchanges of heads_reduce are gfx950's lane-swap instructions: v_permlane32_swap exchanges lanes 32..63 of
+// its first operand with lanes 0..31 of its second (v_permlane16_swap: the odd 16-lane rows of the first with the even
+// rows of the second), so first' + second' is, in the lanes whose bit 5 (bit 4) is clear, the first operand summed over
+// the lane pair, and in the other lanes the second operand summed over the pair: one swap + one add per pair of heads,
+// no select, no ds_bpermute.  (Written as "bit ? v[h1] : v[h0]" the compiler turned the selects of array elements into
+// per-lane indexed reads of the 16-element array: 15 v_cmp + 15 v_cndmask each, ~650 instructions per token.)
+__device__ __forceinline__ float swap32_add(float first, float second) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(first), __float_as_uint(second), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float first, float second) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(first), __float_as_uint(second), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // v[h], h = 0..15: every lane's partial sum for head h  ->  (a, b) = the wave-wide totals of heads g and g + 8, g = lane >> 3
-// (three halving exchanges pair lane bit 5 / 4 / 3 with head bit 2 / 1 / 0, then three plain exchanges inside the group).
+// (three halving exchanges pair lane bit 5 / 4 / 3 with head bit 2 / 1 / 0, then the sum over the 8 lanes of the group).
 __device__ __forceinline__ void heads_reduce(const float (&v)[16], int lane, float& a, float& b) {
-  float w8[8], w4[4], w2[2];
-  const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+  float w8[8], w4[4];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {  // i = (h3, h1, h0); partner heads differ in bit 2
     const int h0 = ((i & 4) << 1) | (i & 3), h1 = h0 | 4;
-    const float keep = b5 ? v[h1] : v[h0], send = b5 ? v[h0] : v[h1];
-    w8[i] = keep + __shfl_xor(send, 32, 64);
+    w8[i] = swap32_add(v[h0], v[h1]);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {  // i = (h3, h0); partner entries of w8 differ in bit 1 of their index
     const int i0 = ((i & 2) << 1) | (i & 1), i1 = i0 | 2;
-    const float keep = b4 ? w8[i1] : w8[i0], send = b4 ? w8[i0] : w8[i1];
-    w4[i] = keep + __shfl_xor(send, 16, 64);
+    w4[i] = swap16_add(w8[i0], w8[i1]);
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {  // i = h3; partner entries of w4 differ in bit 0
-    const int i0 = i << 1, i1 = i0 | 1;
-    const float keep = b3 ? w4[i1] : w4[i0], send = b3 ? w4[i0] : w4[i1];
-    w2[i] = keep + __shfl_xor(send, 8, 64);
-  }
-  a = head_sum8(w2[0]);
-  b = head_sum8(w2[1]);
+  // head bit 0 <-> lane bit 3: both candidates summed over the lane pair (row_ror:8 = lane ^ 8 inside a 16-lane row), then
+  // one select of the finished values
+  const bool b3 = (lane & 8) != 0;
+  const float e0 = add_dpp<0x128>(w4[0]), o0 = add_dpp<0x128>(w4[1]);
+  const float e1 = add_dpp<0x128>(w4[2]), o1 = add_dpp<0x128>(w4[3]);
+  a = head_sum8(b3 ? o0 : e0);
+  b = head_sum8(b3 ? o1 : e1);
 }
 
 __device__ __forceinline__ int64_t token_row(const AbsParams& p, int t, int qy, int qx, int r, int j) {
   const int ry = j / r, rx = j - ry * r, G = p.qside * r;
   return p.window_major ? ((int64_t)t * r * r + j) : ((int64_t)(qy * r + ry) * G + (qx * r + rx));
+}
+
+// the query's window: token j's 1024 channels -> xs[j * 2048 ...] by two 1 KiB LDS-DMA instructions (lane l's 16 bytes of
+// each land at + 16 l: exactly the lane's own two chunks); asynchronous — covered by the s_waitcnt vmcnt(0) in front of
+// the first read
+__device__ __forceinline__ void stage_window(const AbsParams& p, const bf16_t* xb, char* xs, int na, int t, int qy, int qx,
+                                             int lane) {
+  for (int j = 0; j < na; ++j) {
+    const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx + lane * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xr,
+                                     (__attribute__((address_space(3))) void*)(xs + j * 2048), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xr + 512),
+                                     (__attribute__((address_space(3))) void*)(xs + j * 2048 + 1024), 16, 0, 0);
+  }
 }
 
 __device__ __forceinline__ void cvt8(const bf16x8_t& x, float (&f)[8]) {
@@ -113,8 +186,14 @@ __device__ __forceinline__ void cvt8(const bf16x8_t& x, float (&f)[8]) {
 // forward
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
-  __shared__ float pw[4][kMaxKeys][kHeads];  // this wave's absorbed-token probabilities, all heads (broadcast reads)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // per wave: the query's token window (16 x 2 KiB, filled by LDS-DMA: no registers, all rows in flight at once) and the
+  // absorbed-token scores / probabilities of all heads (broadcast reads)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3;
+  char* xs = smem + wave * kWinBytes;
+  float (*pw)[kMaxKeys][kHeads] = reinterpret_cast<float (*)[kMaxKeys][kHeads]>(smem + 4 * kWinBytes);
+  uint32_t (*pp)[kMaxKeys / 2][kHeads] =
+      reinterpret_cast<uint32_t (*)[kMaxKeys / 2][kHeads]>(smem + 4 * kWinBytes + kScratchF32);
   const int64_t nq = (int64_t)p.B * p.qside * p.qside;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -124,6 +203,10 @@ __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
     const int t = (int)(qi - (int64_t)b * p.qside * p.qside);
     const int qy = t / p.qside, qx = t - qy * p.qside;
     const int c0 = lane * 8, c1 = 512 + lane * 8;
+    const int G = p.qside * p.ra;
+    const bf16_t* xb = p.xhat + (int64_t)b * G * G * p.ldx;
+    const uint8_t* mka = p.mask_a ? p.mask_a + qi * na : nullptr;
+    stage_window(p, xb, xs, na, t, qy, qx, lane);
 
     // ---- scores of the directly projected towers' keys (one key per tower: r_i == 1): sd[i][cc] = head g (cc 0) / g + 8 (cc 1)
     float sd[kMaxD][2];
@@ -153,9 +236,6 @@ __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
     float mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int i = 0; i < kMaxD; ++i) { mx[0] = fmaxf(mx[0], sd[i][0]); mx[1] = fmaxf(mx[1], sd[i][1]); }
-    const int G = p.qside * p.ra;
-    const bf16_t* xb = p.xhat + (int64_t)b * G * G * p.ldx;
-    const uint8_t* mka = p.mask_a ? p.mask_a + qi * na : nullptr;
     {
       bf16x8_t u[kHeads][2];
       const bf16_t* ur = p.U + qi * (int64_t)(kHeads * kC);
@@ -165,12 +245,13 @@ __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
         u[h][1] = *reinterpret_cast<const bf16x8_t*>(ur + h * kC + c1);
       }
       const float cb0 = p.cb[qi * kHeads + g], cb1 = p.cb[qi * kHeads + g + 8];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed (and U, the direct towers' rows)
 #pragma unroll 2
       for (int j = 0; j < na; ++j) {
         float s0 = -INFINITY, s1 = -INFINITY;
         if (!(mka && mka[j] == 0)) {
-          const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx;
-          const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xr + c0), x1 = *reinterpret_cast<const bf16x8_t*>(xr + c1);
+          const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + lane * 16);
+          const bf16x8_t x1 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + 1024 + lane * 16);
           float part[kHeads];
 #pragma unroll
           for (int h = 0; h < kHeads; ++h) part[h] = dot8(x1, u[h][1], dot8(x0, u[h][0], 0.f));
@@ -192,10 +273,10 @@ __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
 #pragma unroll
     for (int i = 0; i < kMaxD; ++i)
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) { sd[i][cc] = expf(sd[i][cc] - mx[cc]); l[cc] += sd[i][cc]; }   // exp(-inf) = 0
+      for (int cc = 0; cc < 2; ++cc) { sd[i][cc] = cmb_exp(sd[i][cc] - mx[cc]); l[cc] += sd[i][cc]; }   // exp(-inf) = 0
     for (int j = 0; j < na; ++j) {
-      l[0] += expf(pw[wave][j][g] - mx[0]);
-      l[1] += expf(pw[wave][j][g + 8] - mx[1]);
+      l[0] += cmb_exp(pw[wave][j][g] - mx[0]);
+      l[1] += cmb_exp(pw[wave][j][g + 8] - mx[1]);
     }
     const float inv[2] = {1.0f / l[0], 1.0f / l[1]};
     float* prow0 = p.P + (qi * kHeads + g) * (int64_t)p.nkeys;
@@ -206,16 +287,21 @@ __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
       sd[i][1] *= inv[1];
       if (i < p.ntowers && (lane & 7) == 0) { prow0[i] = sd[i][0]; prow1[i] = sd[i][1]; }
     }
-    for (int j = 0; j < na; ++j) {
-      const float p0 = expf(pw[wave][j][g] - mx[0]) * inv[0], p1 = expf(pw[wave][j][g + 8] - mx[1]) * inv[1];
-      m3v[0] += p0;
-      m3v[1] += p1;
-      __builtin_amdgcn_wave_barrier();   // every lane of the group has read the score before lane 8 g overwrites it
+    // the absorbed tokens' probabilities: fp32 to P (the backward's input), bf16 pairs of consecutive tokens to pp (the
+    // coefficient operand of the token mix below; an odd window's last pair carries a zero)
+    for (int j = 0; j < na; j += 2) {
+      const bool two = j + 1 < na;
+      const float p0a = cmb_exp(pw[wave][j][g] - mx[0]) * inv[0], p1a = cmb_exp(pw[wave][j][g + 8] - mx[1]) * inv[1];
+      const float p0b = two ? cmb_exp(pw[wave][j + 1][g] - mx[0]) * inv[0] : 0.f;
+      const float p1b = two ? cmb_exp(pw[wave][j + 1][g + 8] - mx[1]) * inv[1] : 0.f;
+      m3v[0] += p0a + p0b;
+      m3v[1] += p1a + p1b;
       if ((lane & 7) == 0) {
-        prow0[p.nd + j] = p0;
-        prow1[p.nd + j] = p1;
-        pw[wave][j][g] = p0;
-        pw[wave][j][g + 8] = p1;
+        prow0[p.nd + j] = p0a;
+        prow1[p.nd + j] = p1a;
+        if (two) { prow0[p.nd + j + 1] = p0b; prow1[p.nd + j + 1] = p1b; }
+        pp[wave][j >> 1][g] = pack_bf16(p0a, p0b);
+        pp[wave][j >> 1][g + 8] = pack_bf16(p1a, p1b);
       }
     }
     if ((lane & 7) == 0) {
@@ -240,51 +326,39 @@ __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
       *reinterpret_cast<bf16x8_t*>(orow + c0) = cvt8_bf16(o0[0], o0[1], o0[2], o0[3], o0[4], o0[5], o0[6], o0[7]);
       *reinterpret_cast<bf16x8_t*>(orow + c1) = cvt8_bf16(o1[0], o1[1], o1[2], o1[3], o1[4], o1[5], o1[6], o1[7]);
     }
-    // ---- Xb[h][c] = sum_t p[t][h] xh_t[c], eight heads per pass (128 accumulator registers)
+    // ---- Xb[h][c] = sum_t p[t][h] xh_t[c]: one 512-channel half per pass (16 heads x 8 channels = 128 accumulators),
+    //      two tokens per v_dot2c (a masked token has p = 0 in every head)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-      const uint8_t* mk = mka;
       bf16_t* xo = p.xbar + qi * (int64_t)(kHeads * kC);
 #pragma unroll 1
-      for (int hp = 0; hp < 2; ++hp) {
-        float acc[8][2][8];
+      for (int cc = 0; cc < 2; ++cc) {
+        float acc[kHeads][8];
 #pragma unroll
-        for (int h = 0; h < 8; ++h)
+        for (int h = 0; h < kHeads; ++h)
 #pragma unroll
-          for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[h][cc][e] = 0.f;
-        for (int j = 0; j < na; ++j) {
-          if (mk && mk[j] == 0) continue;
-          const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx;
-          float x0[8], x1[8];
-          cvt8(*reinterpret_cast<const bf16x8_t*>(xr + c0), x0);
-          cvt8(*reinterpret_cast<const bf16x8_t*>(xr + c1), x1);
-          const f32x4_t pa = *reinterpret_cast<const f32x4_t*>(&pw[wave][j][hp * 8]);
-          const f32x4_t pb = *reinterpret_cast<const f32x4_t*>(&pw[wave][j][hp * 8 + 4]);
-          const float ph[8] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
-#pragma unroll
-          for (int h = 0; h < 8; ++h)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              acc[h][0][e] += ph[h] * x0[e];
-              acc[h][1][e] += ph[h] * x1[e];
-            }
+          for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+        const char* xc = xs + cc * 1024 + lane * 16;
+#pragma unroll 1
+        for (int j = 0; j < na; j += 2) {
+          const int j1 = j + 1 < na ? j + 1 : j;   // (coefficient 0)
+          const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(xc + j * 2048);
+          const u32x4_t xb2 = *reinterpret_cast<const u32x4_t*>(xc + j1 * 2048);
+          uint32_t pr[8];
+          interleave8(xa, xb2, pr);
+          mix16(pr, &pp[wave][j >> 1][0], acc);
         }
+        const int cs = cc ? c1 : c0;
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          bf16_t* xrow = xo + (hp * 8 + h) * kC;
-          *reinterpret_cast<bf16x8_t*>(xrow + c0) = cvt8_bf16(acc[h][0][0], acc[h][0][1], acc[h][0][2], acc[h][0][3],
-                                                              acc[h][0][4], acc[h][0][5], acc[h][0][6], acc[h][0][7]);
-          *reinterpret_cast<bf16x8_t*>(xrow + c1) = cvt8_bf16(acc[h][1][0], acc[h][1][1], acc[h][1][2], acc[h][1][3],
-                                                              acc[h][1][4], acc[h][1][5], acc[h][1][6], acc[h][1][7]);
-        }
+        for (int h = 0; h < kHeads; ++h)
+          *reinterpret_cast<bf16x8_t*>(xo + h * kC + cs) = cvt8_bf16(acc[h][0], acc[h][1], acc[h][2], acc[h][3], acc[h][4],
+                                                                      acc[h][5], acc[h][6], acc[h][7]);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // pw is rewritten by this wave's next query
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this query is done before the next window's DMA
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -292,9 +366,16 @@ __global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
 // backward
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sva_abs_bwd_kernel(const AbsParams p) {
-  __shared__ float pw[4][kMaxKeys][kHeads];  // P of the absorbed tokens, all heads
-  __shared__ float dw[4][kMaxKeys][kHeads];  // dS of the absorbed tokens (scale included), all heads
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // per wave: the token window (LDS-DMA), P and dS (scale included) of the absorbed tokens for all heads
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3;
+  char* xs = smem + wave * kWinBytes;
+  float (*pw)[kMaxKeys][kHeads] = reinterpret_cast<float (*)[kMaxKeys][kHeads]>(smem + 4 * kWinBytes);
+  float (*dw)[kMaxKeys][kHeads] = pw + 4;
+  // (P, dS) of every token and head as one bf16 pair; dS of consecutive tokens as one bf16 pair
+  uint32_t (*cf)[kMaxKeys][kHeads] = reinterpret_cast<uint32_t (*)[kMaxKeys][kHeads]>(smem + 4 * kWinBytes + 2 * kScratchF32);
+  uint32_t (*dsp)[kMaxKeys / 2][kHeads] =
+      reinterpret_cast<uint32_t (*)[kMaxKeys / 2][kHeads]>(smem + 4 * kWinBytes + 3 * kScratchF32);
   const int64_t nq = (int64_t)p.B * p.qside * p.qside;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -309,6 +390,7 @@ __global__ void __launch_bounds__(256) sva_abs_bwd_kernel(const AbsParams p) {
     const uint8_t* mka = p.mask_a ? p.mask_a + qi * na : nullptr;
     const int G = p.qside * p.ra;
     const int64_t xbase = (int64_t)b * G * G;
+    stage_window(p, p.xhat + xbase * p.ldx, xs, na, t, qy, qx, lane);
     float q0[8], q1[8], do0[8], do1[8];
     cvt8(*reinterpret_cast<const bf16x8_t*>(p.q + qi * p.ldq + c0), q0);
     cvt8(*reinterpret_cast<const bf16x8_t*>(p.q + qi * p.ldq + c1), q1);
@@ -346,15 +428,15 @@ __global__ void __launch_bounds__(256) sva_abs_bwd_kernel(const AbsParams p) {
         dx[h][1] = *reinterpret_cast<const bf16x8_t*>(dr + h * kC + c1);
       }
       const float dm0 = p.dm3[qi * kHeads + g], dm1 = p.dm3[qi * kHeads + g + 8];
-      const bf16_t* xb = p.xhat + xbase * p.ldx;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed
 #pragma unroll 2
       for (int j = 0; j < na; ++j) {
         float p0 = 0.f, p1 = 0.f, d0 = 0.f, d1 = 0.f;
         if (!(mka && mka[j] == 0)) {
           p0 = prow0[p.nd + j];
           p1 = prow1[p.nd + j];
-          const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx;
-          const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xr + c0), x1 = *reinterpret_cast<const bf16x8_t*>(xr + c1);
+          const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + lane * 16);
+          const bf16x8_t x1 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + 1024 + lane * 16);
           float part[kHeads];
 #pragma unroll
           for (int h = 0; h < kHeads; ++h) part[h] = dot8(x1, dx[h][1], dot8(x0, dx[h][0], 0.f));
@@ -376,22 +458,35 @@ __global__ void __launch_bounds__(256) sva_abs_bwd_kernel(const AbsParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- dS (scale included); d(cb)
+    // ---- dS (scale included); d(cb); the coefficient pairs of the two token mixes below
     float dcb[2] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < kMaxD; ++i) {
       dsd[i][0] = pd[i][0] * (dsd[i][0] - D[0]) * p.scale;
       dsd[i][1] = pd[i][1] * (dsd[i][1] - D[1]) * p.scale;
     }
-    for (int j = 0; j < na; ++j) {
-      const float s0 = pw[wave][j][g] * (dw[wave][j][g] - D[0]) * p.scale;
-      const float s1 = pw[wave][j][g + 8] * (dw[wave][j][g + 8] - D[1]) * p.scale;
-      dcb[0] += s0;
-      dcb[1] += s1;
-      __builtin_amdgcn_wave_barrier();   // every lane of the group has read dP before lane 8 g overwrites it with dS
+    for (int j = 0; j < na; j += 2) {
+      const bool two = j + 1 < na;
+      const float p0a = pw[wave][j][g], p1a = pw[wave][j][g + 8];
+      const float s0a = p0a * (dw[wave][j][g] - D[0]) * p.scale, s1a = p1a * (dw[wave][j][g + 8] - D[1]) * p.scale;
+      float p0b = 0.f, p1b = 0.f, s0b = 0.f, s1b = 0.f;
+      if (two) {
+        p0b = pw[wave][j + 1][g];
+        p1b = pw[wave][j + 1][g + 8];
+        s0b = p0b * (dw[wave][j + 1][g] - D[0]) * p.scale;
+        s1b = p1b * (dw[wave][j + 1][g + 8] - D[1]) * p.scale;
+      }
+      dcb[0] += s0a + s0b;
+      dcb[1] += s1a + s1b;
       if ((lane & 7) == 0) {
-        dw[wave][j][g] = s0;
-        dw[wave][j][g + 8] = s1;
+        cf[wave][j][g] = pack_bf16(p0a, s0a);
+        cf[wave][j][g + 8] = pack_bf16(p1a, s1a);
+        if (two) {
+          cf[wave][j + 1][g] = pack_bf16(p0b, s0b);
+          cf[wave][j + 1][g + 8] = pack_bf16(p1b, s1b);
+        }
+        dsp[wave][j >> 1][g] = pack_bf16(s0a, s0b);
+        dsp[wave][j >> 1][g + 8] = pack_bf16(s1a, s1b);
       }
     }
     if ((lane & 7) == 0) {
@@ -434,13 +529,13 @@ __global__ void __launch_bounds__(256) sva_abs_bwd_kernel(const AbsParams p) {
       *reinterpret_cast<bf16x8_t*>(dqr + c0) = cvt8_bf16(dq0[0], dq0[1], dq0[2], dq0[3], dq0[4], dq0[5], dq0[6], dq0[7]);
       *reinterpret_cast<bf16x8_t*>(dqr + c1) = cvt8_bf16(dq1[0], dq1[1], dq1[2], dq1[3], dq1[4], dq1[5], dq1[6], dq1[7]);
     }
-    // ---- absorbed tower, one 512-channel half per pass:
-    //      d(xh_t)[c] = sum_h P[t][h] dXb[h][c] + dS[t][h] U[h][c];   dU[h][c] = sum_t dS[t][h] xh_t[c]
+    // ---- absorbed tower, one 512-channel half per pass, two terms per v_dot2c:
+    //      d(xh_t)[c] = sum_h P[t][h] dXb[h][c] + dS[t][h] U[h][c]     ((dXb, U) element pairs x (P, dS) pairs)
+    //      dU[h][c]   = sum_t dS[t][h] xh_t[c]                          (token-pair element pairs x dS pairs)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-      const bf16_t* xb = p.xhat + xbase * p.ldx;
       bf16_t* dxb = p.dxhat + xbase * p.lddx;
       const bf16_t* ur = p.U + qi * (int64_t)(kHeads * kC);
       const bf16_t* dr = p.dxbar + qi * (int64_t)(kHeads * kC);
@@ -448,52 +543,56 @@ __global__ void __launch_bounds__(256) sva_abs_bwd_kernel(const AbsParams p) {
 #pragma unroll 1
       for (int cc = 0; cc < 2; ++cc) {
         const int cs = cc ? c1 : c0;
-        bf16x8_t uc[kHeads], dc[kHeads];
-        float du[kHeads][8];
+        {
+          uint32_t pr[kHeads][8];
 #pragma unroll
-        for (int h = 0; h < kHeads; ++h) {
-          uc[h] = *reinterpret_cast<const bf16x8_t*>(ur + h * kC + cs);
-          dc[h] = *reinterpret_cast<const bf16x8_t*>(dr + h * kC + cs);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) du[h][e] = 0.f;
-        }
+          for (int h = 0; h < kHeads; ++h)
+            interleave8(*reinterpret_cast<const u32x4_t*>(dr + h * kC + cs), *reinterpret_cast<const u32x4_t*>(ur + h * kC + cs),
+                        pr[h]);
 #pragma unroll 1
-        for (int j = 0; j < na; ++j) {
-          const int64_t row = token_row(p, t, qy, qx, p.ra, j);
-          float dxv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (!(mka && mka[j] == 0)) {  // (a masked token has P = dS = 0 in every head: its gradient row is zero)
-            float xf[8];
-            cvt8(*reinterpret_cast<const bf16x8_t*>(xb + row * p.ldx + cs), xf);
+          for (int j = 0; j < na; ++j) {   // (a masked token has P = dS = 0 in every head: its gradient row is zero)
+            float dx[2][8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dx[0][e] = dx[1][e] = 0.f;
 #pragma unroll
             for (int hq = 0; hq < 4; ++hq) {
-              const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(&pw[wave][j][hq * 4]);
-              const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(&dw[wave][j][hq * 4]);
+              const u32x4_t c4 = *reinterpret_cast<const u32x4_t*>(&cf[wave][j][hq * 4]);
 #pragma unroll
-              for (int hh = 0; hh < 4; ++hh) {
-                const int h = hq * 4 + hh;
-                // the packed operands are converted HERE, per use: left visible, the bf16 -> fp32 converts are loop-invariant
-                // and the compiler keeps 256 unpacked copies live across the token loop (spills)
-                bf16x8_t dd = dc[h], uu = uc[h];
-                asm volatile("" : "+v"(dd), "+v"(uu));
+              for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  dxv[e] += p4[hh] * (float)dd[e] + d4[hh] * (float)uu[e];
-                  du[h][e] += d4[hh] * xf[e];
-                }
-              }
+                for (int e = 0; e < 8; ++e) dx[hh & 1][e] = dot2(pr[hq * 4 + hh][e], c4[hh], dx[hh & 1][e]);
             }
+            const int64_t row = token_row(p, t, qy, qx, p.ra, j);
+            *reinterpret_cast<bf16x8_t*>(dxb + row * p.lddx + cs) =
+                cvt8_bf16(dx[0][0] + dx[1][0], dx[0][1] + dx[1][1], dx[0][2] + dx[1][2], dx[0][3] + dx[1][3],
+                          dx[0][4] + dx[1][4], dx[0][5] + dx[1][5], dx[0][6] + dx[1][6], dx[0][7] + dx[1][7]);
           }
-          *reinterpret_cast<bf16x8_t*>(dxb + row * p.lddx + cs) =
-              cvt8_bf16(dxv[0], dxv[1], dxv[2], dxv[3], dxv[4], dxv[5], dxv[6], dxv[7]);
         }
+        {
+          float du[kHeads][8];
 #pragma unroll
-        for (int h = 0; h < kHeads; ++h)
-          *reinterpret_cast<bf16x8_t*>(duo + h * kC + cs) =
-              cvt8_bf16(du[h][0], du[h][1], du[h][2], du[h][3], du[h][4], du[h][5], du[h][6], du[h][7]);
+          for (int h = 0; h < kHeads; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) du[h][e] = 0.f;
+          const char* xc = xs + cc * 1024 + lane * 16;
+#pragma unroll 1
+          for (int j = 0; j < na; j += 2) {
+            const int j1 = j + 1 < na ? j + 1 : j;   // (coefficient 0)
+            const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(xc + j * 2048);
+            const u32x4_t xb2 = *reinterpret_cast<const u32x4_t*>(xc + j1 * 2048);
+            uint32_t xp[8];
+            interleave8(xa, xb2, xp);
+            mix16(xp, &dsp[wave][j >> 1][0], du);
+          }
+#pragma unroll
+          for (int h = 0; h < kHeads; ++h)
+            *reinterpret_cast<bf16x8_t*>(duo + h * kC + cs) =
+                cvt8_bf16(du[h][0], du[h][1], du[h][2], du[h][3], du[h][4], du[h][5], du[h][6], du[h][7]);
+        }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // pw / dw are rewritten by this wave's next query
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this query is done before the next window's DMA
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -540,7 +639,14 @@ extern "C" int cmb_sva_abs_fwd(const cmb_sva_abs_desc* d, void* stream) {
   if (nq == 0) return CMB_OK;
   int64_t blocks = (nq + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(sva_abs_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sva_abs_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kSmemFwd) != hipSuccess)
+      return CMB_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sva_abs_fwd_kernel, dim3((unsigned)blocks), dim3(256), kSmemFwd, (hipStream_t)stream, p);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }
@@ -553,7 +659,14 @@ extern "C" int cmb_sva_abs_bwd(const cmb_sva_abs_desc* d, void* stream) {
   if (nq == 0) return CMB_OK;
   int64_t blocks = (nq + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(sva_abs_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sva_abs_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kSmemBwd) != hipSuccess)
+      return CMB_ERR_LAUNCH;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(sva_abs_bwd_kernel, dim3((unsigned)blocks), dim3(256), kSmemBwd, (hipStream_t)stream, p);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

@@ -105,6 +105,11 @@ def test_absorbed_attention_matches_direct_reference(dev, B, qside, ra, nsmall, 
     checks += [(f"kv{i}", a.grad, b.grad) for i, (a, b) in enumerate(zip(kv_hip, kv_ref))]
     for name, a, b in checks:
         assert a is not None and b is not None, name
+        if name == "bk" and nsmall == 0:
+            # b_k . q_h shifts EVERY key's score of a (query, head) when no other tower is present: softmax is shift
+            # invariant, the gradient is mathematically zero and both sides hold rounding noise only
+            assert a.abs().max().item() < 1e-2 * leaves_hip["bv"].grad.abs().max().item()
+            continue
         e = rel_err(a, b)
         assert e < 3e-2, (name, e)
     # masked tokens of the windowed tower: exactly zero gradient rows
