@@ -391,6 +391,7 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   p.a_scale = nullptr; p.b_scale = nullptr;
   p.batch = d->batch > 1 ? d->batch : 1;
   p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
+  p.slab_rows = p.M;
   int splits = d->split_k > 1 ? d->split_k : 1;
   if (p.batch > 1) {
     // batched problems: plain epilogue (alpha / activation / out dtype), no split-K, 16-byte aligned strides
@@ -464,6 +465,68 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   return CMB_OK;
 }
 
+// C[M,N] = alpha * At[K,M]^T Bt[K,N] (+ beta C): descriptor checks, split-K slabs and their reduction around gemm_tn.hip
+int gemm_tn_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
+  if (d->dtype != CMB_BF16 || (d->out_dtype != CMB_F32 && d->out_dtype != CMB_BF16)) return CMB_ERR_BAD_ARG;
+  if (d->bias || d->colscale || d->residual || d->pre_out || d->act != CMB_ACT_NONE || d->a_map.n1 != 0) return CMB_ERR_BAD_ARG;
+  if (d->M % 8 != 0 || d->N % 8 != 0) return CMB_ERR_SHAPE;
+  const int64_t lda = d->a_map.s2;
+  if (!cmb_aligned16(d->A) || !cmb_aligned16(d->B) || (lda * 2) % 16 != 0 || (d->ldb * 2) % 16 != 0 || lda < d->M || d->ldb < d->N)
+    return CMB_ERR_ALIGNMENT;
+  GemmParams p;
+  p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
+  p.A = (const char*)d->A; p.a_map = make_rowmap(d->a_map);
+  p.B = (const char*)d->B; p.ldb = d->ldb;
+  p.C = (char*)d->C; p.c_map = make_rowmap(d->c_map);
+  p.bias = nullptr; p.colscale = nullptr;
+  p.R = nullptr; p.r_map = make_rowmap(d->r_map);
+  p.P = nullptr; p.p_map = make_rowmap(d->p_map);
+  p.act = CMB_ACT_NONE; p.alpha = d->alpha; p.beta = d->beta;
+  p.out_f32 = (d->out_dtype == CMB_F32);
+  p.slabs = nullptr;
+  p.k_per_split = p.K;
+  p.a_scale = nullptr; p.b_scale = nullptr;
+  p.batch = d->batch > 1 ? d->batch : 1;
+  p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
+  p.slab_rows = p.M;
+  int splits = d->split_k > 1 ? d->split_k : 1;
+  if (p.batch > 1) {
+    if ((p.a_bs * 2) % 16 || (p.b_bs * 2) % 16 || (p.c_bs * 2) % 16) return CMB_ERR_ALIGNMENT;
+    // split-K of a batch: the slabs are [split][batch * M][N], reduced as ONE matrix — the results must be contiguous
+    if (splits > 1 && (d->c_map.n1 != 0 || d->c_map.s2 != d->N || p.c_bs != (int64_t)p.M * p.N)) return CMB_ERR_BAD_ARG;
+  }
+  if (splits > 1) {
+    const int ksteps = (p.K + 63) / 64;
+    if (splits > ksteps) splits = ksteps;
+    const int per = (ksteps + splits - 1) / splits;
+    splits = (ksteps + per - 1) / per;
+    if (splits > 1) {
+      p.k_per_split = per * 64;
+      p.slab_rows = p.batch * p.M;
+      const int64_t need = (int64_t)splits * p.slab_rows * p.N * 4;
+      if (!d->workspace || d->workspace_bytes < need) return CMB_ERR_WORKSPACE;
+      p.slabs = (float*)d->workspace;
+    }
+  }
+  g_last_kernel = 1281;
+  const int rc = launch_gemm_tn_bf16(p, splits, s);
+  if (rc != CMB_OK) return rc;
+  if (p.slabs) {
+    p.M = p.slab_rows;   // (a batch's results are one contiguous [batch * M, N] matrix)
+    const int64_t groups = (int64_t)p.M * (p.N / 8);
+    int blocks = (int)((groups + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (p.out_f32)
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, p.slabs, splits, p.M, p.N, p.C, p.c_map,
+                         p.alpha, p.beta);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, p.slabs, splits, p.M, p.N, p.C, p.c_map,
+                         p.alpha, p.beta);
+    CMB_CHECK_LAUNCH();
+  }
+  return CMB_OK;
+}
+
 }  // namespace
 
 extern "C" int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint) {
@@ -493,6 +556,12 @@ extern "C" int cmb_gemm_policy_clear(void) {
 extern "C" int cmb_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int64_t cmb_gemm_tail_rows(int64_t M, int64_t N) { return tail_split_rows_mnk(M, N); }
+
+extern "C" int cmb_gemm_tn(const cmb_gemm_desc* d, void* stream) {
+  if (!d || !d->A || !d->B || !d->C) return CMB_ERR_BAD_ARG;
+  if (d->M <= 0 || d->N <= 0 || d->K < 0) return CMB_ERR_BAD_ARG;
+  return gemm_tn_dispatch(d, (hipStream_t)stream);
+}
 
 extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return CMB_ERR_BAD_ARG;

@@ -26,6 +26,7 @@ struct GemmParams {
   const float* b_scale;
   int batch;                 // > 1: blockIdx.z walks independent problems of the same shape (128 x 128 kernel only)
   int64_t a_bs, b_bs, c_bs;  // element strides of A / B / C between consecutive problems of a batch
+  int slab_rows;             // rows of one split-K slab (= M; batch * M for cmb_gemm_tn's batched split-K)
 };
 
 // storage tag of an OCP e4m3fn operand byte (gfx950 native fp8)
@@ -91,7 +92,7 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 template <typename T, int ACT>
 __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int gm, int gn, float (&v)[8]) {
   if (p.slabs) {  // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
-    Vec8<float>::store(p.slabs + ((int64_t)kz * p.M + gm) * p.N + gn, v);
+    Vec8<float>::store(p.slabs + ((int64_t)kz * p.slab_rows + gm) * p.N + gn, v);
     return;
   }
   if (p.a_scale || p.b_scale) {  // fp8 operands: undo the row-wise quantisation scales
@@ -163,5 +164,9 @@ int launch_gemm256_bf16(GemmParams& p, int splits, int sched, hipStream_t s);
 // gemm_p5.hip: persistent 256x256 bf16 tile, 4 waves x (128 x 128), 64-deep tiles, the tile's fragments in registers,
 // two LDS buffers (gemm_nt_p5_kernel)
 int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s);
+
+// gemm_tn.hip: C[M,N] = At[K,M]^T Bt[K,N] (both operands row-major over the contraction rows; p.a_map.s2 = lda, p.K = rows),
+// 128 x 128 tile, transposing LDS reads
+int launch_gemm_tn_bf16(GemmParams& p, int splits, hipStream_t s);
 
 }  // namespace cmb_gemm_detail

@@ -15,25 +15,38 @@
 // the output; and the backward of exactly that.
 //
 // Roofline class: HBM (three [Bq, 16, 1024] bf16 tensors — U, Xb, and the tower's xh — read or written once or twice).
-// One wave owns one query; a lane owns channels [8 l, 8 l + 8) and [512 + 8 l, 512 + 8 l + 8) of every 1024-wide row
-// (16-byte accesses, a wave-instruction covers 1 KiB contiguous).  The 16 x 16 x 1024 products of a query run on
-// v_dot2c_f32_bf16 over packed operands; a 16-value butterfly (lane bits 5, 4, 3 <-> head bits 2, 1, 0) leaves lane group
-// g = lane >> 3 with the sums of heads g and g + 8 — the same head ownership sva_attn.hip's per-chunk dot products have.
+// One wave owns one query.  A query's window is 16 tokens, the layer has 16 heads: every product of the query is a
+// 16 x 16 output tile over 1024 channels, i.e. MFMA-shaped with nothing to pad:
+//     S[t][h]      = sum_c X[t][c] U[h][c]          32 x v_mfma_f32_16x16x32_bf16   (A: X rows from LDS, B: U rows from HBM)
+//     Xb^T[c][h]   = sum_t X^T[c][t] P[t][h]        64 x v_mfma_f32_16x16x16_bf16   (A: ds_read_b64_tr_b16 of X, B: P in registers)
+//     dP[t][h]     = sum_c X[t][c] dXb[h][c]        as S
+//     dU^T[c][h]   = sum_t X^T[c][t] dS[t][h]       as Xb
+//     dX^T[c][t]   = sum_k W^T[c][k] Coef[k][t]     64 x 16x16x32, k = (dXb heads, U heads), Coef = (P^T; dS^T)
+// The window lands in LDS by LDS-DMA (2 KiB per token, no registers); the MFMA output layout (lane = column, 4 rows per
+// lane quad) of S IS the B-operand layout of the 16x16x16 product, so P and dS never leave the registers between the
+// softmax and the token mix.  ds_read_b64_tr_b16 hands each lane 4 tokens (or heads) of ONE channel out of a row-major
+// image; its four 8-byte pieces per row are aimed at channels 8p + 4T + e so that the two tiles T = 0, 1 of a 32-channel
+// group leave a lane with 8 consecutive channels: 16-byte stores.  (The v_dot2c / v_fma forms of these products were
+// VALU-bound at one wave per SIMD: 372 us forward and 646 us backward per launch of 9216 queries against ~130 / ~220 us
+// of HBM traffic.)
 #include "common.h"
 
 namespace {
 
 constexpr int kHeads = 16, kHd = 64, kC = 1024, kMaxKeys = 16;
 constexpr int kWinBytes = kMaxKeys * kC * 2;                       // one wave's token window in LDS: 32 KiB
-constexpr int kScratchF32 = 4 * kMaxKeys * kHeads * 4;            // [wave][token][head] fp32: 4 KiB
-constexpr int kScratchPair = 4 * (kMaxKeys / 2) * kHeads * 4;     // [wave][token pair][head] bf16x2: 2 KiB
-constexpr int kSmemFwd = 4 * kWinBytes + kScratchF32 + kScratchPair;                    // + scores, + P pairs
-constexpr int kSmemBwd = 4 * kWinBytes + 2 * kScratchF32 + kScratchF32 + kScratchPair;  // + P, dP, + (P, dS), + dS pairs
-constexpr int kMaxD = 4;  // directly projected towers (one key each) beside the absorbed one
+constexpr int kCoefBytes = kMaxKeys * 32 * 2;                      // backward: (P | dS)[t][32] bf16 per wave
+constexpr int kSmemFwd = kWinBytes;                  // one wave per workgroup: 5 (forward) / 4 (backward) per CU
+constexpr int kSmemBwd = kWinBytes + kCoefBytes;
+constexpr int kMaxD = 4;      // directly projected towers (one key each) beside the absorbed one
+constexpr int kPStride = 20;  // P row of a (query, head): [0, 4) the direct towers' keys, [4, 20) the absorbed tokens
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
 
 struct AbsParams {
   int B, qside, ntowers, window_major;
@@ -49,7 +62,6 @@ struct AbsParams {
   bf16_t* xbar;
   float* m3;
   float* P;
-  int nd, nkeys;  // direct keys per query, all keys per query
   // backward
   const bf16_t* dout; int64_t lddo;
   const bf16_t* dxbar;
@@ -62,100 +74,26 @@ struct AbsParams {
   float scale;
 };
 
-// x + (x of the lane `ctrl` names), one v_add_f32_dpp
-template <int CTRL>
-__device__ __forceinline__ float add_dpp(float x) {
-  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+// reductions over the four lanes that share a head (lane & 15): lane ^ 16, lane ^ 32
+__device__ __forceinline__ float qsum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
 }
-
-// sum over the 8 lanes of a group (lane ^ 1, lane ^ 2, 7 - lane: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror)
-__device__ __forceinline__ float head_sum8(float v) {
-  v = add_dpp<0xB1>(v);
-  v = add_dpp<0x4E>(v);
-  v = add_dpp<0x141>(v);
+__device__ __forceinline__ float qmax(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 
-// 8 bf16 . 8 bf16 accumulated into acc (4 x v_dot2c_f32_bf16)
-__device__ __forceinline__ float dot8(const bf16x8_t& a, const bf16x8_t& b, float acc) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const bf16x2_t x = {a[2 * i], a[2 * i + 1]}, y = {b[2 * i], b[2 * i + 1]};
-    acc = __builtin_amdgcn_fdot2_f32_bf16(x, y, acc, false);
-  }
-  return acc;
-}
-
-// packed-pair arithmetic of the token-mix products.  A sum over tokens (or heads) of coefficient x row-element runs two terms
-// per v_dot2c_f32_bf16: the row elements of two tokens are interleaved into bf16 pairs (v_perm_b32, once per pair of rows)
-// and the two wave-uniform coefficients travel as one bf16 pair read from LDS (broadcast) — no bf16 -> fp32 converts and
-// half the multiply instructions of the fp32 FMA form; the coefficients (probabilities, dS) are rounded to bf16, as the P
-// operand of every MFMA attention kernel is.
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
-__device__ __forceinline__ uint32_t pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }  // {a.lo, b.lo}
-__device__ __forceinline__ uint32_t pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }  // {a.hi, b.hi}
-__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc) {
-  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
-}
-// rows a, b (8 bf16 each) -> pr[e] = {a[e], b[e]}
-__device__ __forceinline__ void interleave8(const u32x4_t& a, const u32x4_t& b, uint32_t (&pr)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    pr[2 * i] = pair_lo(a[i], b[i]);
-    pr[2 * i + 1] = pair_hi(a[i], b[i]);
-  }
-}
-// acc[h][e] += pr[e] . c[h] for the 16 heads' coefficient pairs at cp (LDS, wave-uniform address)
-__device__ __forceinline__ void mix16(const uint32_t (&pr)[8], const uint32_t* cp, float (&acc)[kHeads][8]) {
-#pragma unroll
-  for (int hq = 0; hq < 4; ++hq) {
-    const u32x4_t c4 = *reinterpret_cast<const u32x4_t*>(cp + hq * 4);
-#pragma unroll
-    for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[hq * 4 + hh][e] = dot2(pr[e], c4[hh], acc[hq * 4 + hh][e]);
-  }
-}
-
-// the halving exchanges of heads_reduce are gfx950's lane-swap instructions: v_permlane32_swap exchanges lanes 32..63 of
-// its first operand with lanes 0..31 of its second (v_permlane16_swap: the odd 16-lane rows of the first with the even
-// rows of the second), so first' + second' is, in the lanes whose bit 5 (bit 4) is clear, the first operand summed over
-// the lane pair, and in the other lanes the second operand summed over the pair: one swap + one add per pair of heads,
-// no select, no ds_bpermute.  (Written as "bit ? v[h1] : v[h0]" the compiler turned the selects of array elements into
-// per-lane indexed reads of the 16-element array: 15 v_cmp + 15 v_cndmask each, ~650 instructions per token.)
-__device__ __forceinline__ float swap32_add(float first, float second) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(first), __float_as_uint(second), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float swap16_add(float first, float second) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(first), __float_as_uint(second), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// v[h], h = 0..15: every lane's partial sum for head h  ->  (a, b) = the wave-wide totals of heads g and g + 8, g = lane >> 3
-// (three halving exchanges pair lane bit 5 / 4 / 3 with head bit 2 / 1 / 0, then the sum over the 8 lanes of the group).
-__device__ __forceinline__ void heads_reduce(const float (&v)[16], int lane, float& a, float& b) {
-  float w8[8], w4[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {  // i = (h3, h1, h0); partner heads differ in bit 2
-    const int h0 = ((i & 4) << 1) | (i & 3), h1 = h0 | 4;
-    w8[i] = swap32_add(v[h0], v[h1]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {  // i = (h3, h0); partner entries of w8 differ in bit 1 of their index
-    const int i0 = ((i & 2) << 1) | (i & 1), i1 = i0 | 2;
-    w4[i] = swap16_add(w8[i0], w8[i1]);
-  }
-  // head bit 0 <-> lane bit 3: both candidates summed over the lane pair (row_ror:8 = lane ^ 8 inside a 16-lane row), then
-  // one select of the finished values
-  const bool b3 = (lane & 8) != 0;
-  const float e0 = add_dpp<0x128>(w4[0]), o0 = add_dpp<0x128>(w4[1]);
-  const float e1 = add_dpp<0x128>(w4[2]), o1 = add_dpp<0x128>(w4[3]);
-  a = head_sum8(b3 ? o0 : e0);
-  b = head_sum8(b3 ? o1 : e1);
+__device__ __forceinline__ s16x4_t pack4_bf16(float a, float b, float c, float d) {
+  typedef uint32_t u32x2_v __attribute__((ext_vector_type(2)));
+  const u32x2_v w = {pack_bf16(a, b), pack_bf16(c, d)};
+  return __builtin_bit_cast(s16x4_t, w);
 }
 
 __device__ __forceinline__ int64_t token_row(const AbsParams& p, int t, int qy, int qx, int r, int j) {
@@ -163,436 +101,358 @@ __device__ __forceinline__ int64_t token_row(const AbsParams& p, int t, int qy, 
   return p.window_major ? ((int64_t)t * r * r + j) : ((int64_t)(qy * r + ry) * G + (qx * r + rx));
 }
 
-// the query's window: token j's 1024 channels -> xs[j * 2048 ...] by two 1 KiB LDS-DMA instructions (lane l's 16 bytes of
-// each land at + 16 l: exactly the lane's own two chunks); asynchronous — covered by the s_waitcnt vmcnt(0) in front of
-// the first read
+// LDS images.  A row is split into 1 KiB halves of 64 16-byte slots (8 channels each); slot c of row r is stored at slot
+// c ^ 4 (r & 15) of its half, so that the 16 rows a wave instruction touches at ONE channel offset spread over the banks
+// (rows are 1 or 2 KiB apart: without the rotation all of them start on bank 0 and a ds_read_b128 of the score product
+// runs 16-way conflicted).  LDS-DMA writes lane l's 16 bytes at + 16 l, so the rotation is applied to the lane's SOURCE.
+//
+// the query's window: token j's 1024 channels -> xs[j * 2048 ...] by two 1 KiB LDS-DMA instructions; asynchronous —
+// covered by the s_waitcnt vmcnt(0) in front of the first read
 __device__ __forceinline__ void stage_window(const AbsParams& p, const bf16_t* xb, char* xs, int na, int t, int qy, int qx,
                                              int lane) {
   for (int j = 0; j < na; ++j) {
-    const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx + lane * 8;
+    const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx + ((lane ^ (4 * j)) & 63) * 8;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xr,
                                      (__attribute__((address_space(3))) void*)(xs + j * 2048), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xr + 512),
                                      (__attribute__((address_space(3))) void*)(xs + j * 2048 + 1024), 16, 0, 0);
   }
 }
+// window rows [na, 16) of a smaller window: zeros (their probabilities are zero, but 0 x stale LDS bits may be NaN)
+__device__ __forceinline__ void zero_tail_rows(char* xs, int na, int lane) {
+  const u32x4_t z = {0u, 0u, 0u, 0u};
+  for (int off = na * 2048 + lane * 16; off < kWinBytes; off += 1024) *reinterpret_cast<u32x4_t*>(xs + off) = z;
+}
 
-__device__ __forceinline__ void cvt8(const bf16x8_t& x, float (&f)[8]) {
+__device__ __forceinline__ void cvt8(const bf16x8_t& x, float* f) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) f[e] = (float)x[e];
+}
+struct Raw16 { bf16x8_t lo, hi; };   // 16 consecutive channels as loaded
+__device__ __forceinline__ Raw16 load16(const bf16_t* p) {
+  Raw16 r;
+  r.lo = *reinterpret_cast<const bf16x8_t*>(p);
+  r.hi = *reinterpret_cast<const bf16x8_t*>(p + 8);
+  return r;
+}
+__device__ __forceinline__ void cvt16(const Raw16& r, float (&f)[16]) {
+  cvt8(r.lo, f);
+  cvt8(r.hi, f + 8);
+}
+__device__ __forceinline__ void store16f(bf16_t* p, const float (&f)[16]) {
+  *reinterpret_cast<bf16x8_t*>(p) = cvt8_bf16(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+  *reinterpret_cast<bf16x8_t*>(p + 8) = cvt8_bf16(f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15]);
+}
+
+// acc[t][h] += sum_c X[t][c] Y[h][c] over the 1024 channels: lane (i = lane & 15, qd = lane >> 4) feeds row i of X (LDS)
+// and row i of Y (registers yv[s]: channels [32 s + 8 qd, + 8)) to 32 MFMAs on four independent accumulators
+__device__ __forceinline__ f32x4_t rows_dot(const char* xs, const bf16x8_t (&yv)[32], int i, int qd) {
+  f32x4_t acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const char* xr = xs + i * 2048 + qd * 16;
+#pragma unroll
+  for (int s = 0; s < 32; ++s) {
+    const bf16x8_t xa = *reinterpret_cast<const bf16x8_t*>(xr + (s >> 4) * 1024 + (((s & 15) ^ i) << 6));
+    acc[s & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, yv[s], acc[s & 3], 0, 0, 0);
+  }
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
+// out[h][c] = sum_t coef[t][h] X[t][c] for all 1024 channels (Xb from P, dU from dS): per 32-channel group two
+// transposing LDS reads + two 16x16x16 MFMAs; lane (i, qd) ends with head i, channels [32 cg + 8 qd, + 8): one 16-byte store
+__device__ __forceinline__ void token_mix(const char* xs, s16x4_t coef, bf16_t* orow, int i, int qd) {
+  // transposing read: this lane supplies row tk = 4 qd + i / 4 (token), piece i % 4 (channels 8 p + 4 T + e of the group)
+  const int tk = 4 * qd + (i >> 2);
+  const char* xr = xs + tk * 2048 + (i & 3) * 16;
+  bf16_t* op = orow + i * kC + qd * 8;
+#pragma unroll 4
+  for (int cg = 0; cg < 32; ++cg) {
+    const char* a = xr + (cg >> 4) * 1024 + (((cg & 15) ^ tk) << 6);
+    const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)a);
+    const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a + 8));
+    const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4_t d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, coef, z, 0, 0, 0);
+    const f32x4_t d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, coef, z, 0, 0, 0);
+    *reinterpret_cast<bf16x8_t*>(op + cg * 32) = cvt8_bf16(d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sva_abs_fwd_kernel(const AbsParams p) {
+__global__ void __launch_bounds__(64) sva_abs_fwd_kernel(const AbsParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // per wave: the query's token window (16 x 2 KiB, filled by LDS-DMA: no registers, all rows in flight at once) and the
-  // absorbed-token scores / probabilities of all heads (broadcast reads)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3;
-  char* xs = smem + wave * kWinBytes;
-  float (*pw)[kMaxKeys][kHeads] = reinterpret_cast<float (*)[kMaxKeys][kHeads]>(smem + 4 * kWinBytes);
-  uint32_t (*pp)[kMaxKeys / 2][kHeads] =
-      reinterpret_cast<uint32_t (*)[kMaxKeys / 2][kHeads]>(smem + 4 * kWinBytes + kScratchF32);
+  const int lane = threadIdx.x, i = lane & 15, qd = lane >> 4;
+  char* xs = smem;
   const int64_t nq = (int64_t)p.B * p.qside * p.qside;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int na = p.ra * p.ra;
-  for (int64_t qi = wave_global; qi < nq; qi += nwaves) {
+  if (na < kMaxKeys) zero_tail_rows(xs, na, lane);
+  for (int64_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const int b = (int)(qi / (p.qside * p.qside));
     const int t = (int)(qi - (int64_t)b * p.qside * p.qside);
     const int qy = t / p.qside, qx = t - qy * p.qside;
-    const int c0 = lane * 8, c1 = 512 + lane * 8;
     const int G = p.qside * p.ra;
-    const bf16_t* xb = p.xhat + (int64_t)b * G * G * p.ldx;
-    const uint8_t* mka = p.mask_a ? p.mask_a + qi * na : nullptr;
-    stage_window(p, xb, xs, na, t, qy, qx, lane);
-
-    // ---- scores of the directly projected towers' keys (one key per tower: r_i == 1): sd[i][cc] = head g (cc 0) / g + 8 (cc 1)
-    float sd[kMaxD][2];
+    // ---- everything the query reads from HBM is requested here, in one round trip
+    stage_window(p, p.xhat + (int64_t)b * G * G * p.ldx, xs, na, t, qy, qx, lane);
+    // U[h = i][32 s + 8 qd ...]: the B operands of the score product
+    bf16x8_t u[32];
     {
-      const bf16_t* qr = p.q + qi * p.ldq;
-      float q0[8], q1[8];
-      cvt8(*reinterpret_cast<const bf16x8_t*>(qr + c0), q0);
-      cvt8(*reinterpret_cast<const bf16x8_t*>(qr + c1), q1);
+      const bf16_t* ur = p.U + qi * (int64_t)(kHeads * kC) + i * kC + qd * 8;
 #pragma unroll
-      for (int i = 0; i < kMaxD; ++i) {
-        sd[i][0] = -INFINITY;
-        sd[i][1] = -INFINITY;
-        if (i < p.ntowers && !(p.mask[i] && p.mask[i][qi] == 0)) {
-          const bf16_t* kr = p.kv[i] + qi * p.ldkv[i];   // r == 1: the query's own token, same index in both layouts
-          float k0[8], k1[8];
-          cvt8(*reinterpret_cast<const bf16x8_t*>(kr + c0), k0);
-          cvt8(*reinterpret_cast<const bf16x8_t*>(kr + c1), k1);
-          float s0 = 0.f, s1 = 0.f;
+      for (int s = 0; s < 32; ++s) u[s] = *reinterpret_cast<const bf16x8_t*>(ur + s * 32);
+    }
+    // the directly projected towers (one key each, r == 1): lane (i, qd) owns channels [64 i + 16 qd, + 16) of head i
+    const int ch = i * kHd + qd * 16;
+    const Raw16 qraw = load16(p.q + qi * p.ldq + ch);
+    Raw16 kraw[kMaxD], vraw[kMaxD];
+    bool live[kMaxD];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s0 += q0[e] * k0[e]; s1 += q1[e] * k1[e]; }
-          sd[i][0] = head_sum8(s0) * p.scale;
-          sd[i][1] = head_sum8(s1) * p.scale;
+    for (int d = 0; d < kMaxD; ++d) {
+      live[d] = d < p.ntowers && !(p.mask[d] && p.mask[d][qi] == 0);
+      if (live[d]) {
+        const bf16_t* kr = p.kv[d] + qi * p.ldkv[d] + ch;   // r == 1: the query's own token, same index in both layouts
+        kraw[d] = load16(kr);
+        vraw[d] = load16(kr + kC);
+      }
+    }
+    const float cbh = p.cb[qi * kHeads + i];
+    uint32_t valid = 0;   // bit r: token 4 qd + r exists and may be attended
+    {
+      const uint8_t* mka = p.mask_a ? p.mask_a + qi * na : nullptr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tk = 4 * qd + r;
+        if (tk < na && !(mka && mka[tk] == 0)) valid |= 1u << r;
+      }
+    }
+    float sd[kMaxD];
+    {
+      float qv[16];
+      cvt16(qraw, qv);
+#pragma unroll
+      for (int d = 0; d < kMaxD; ++d) {
+        sd[d] = -INFINITY;
+        if (live[d]) {
+          float kf[16];
+          cvt16(kraw[d], kf);
+          float acc = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc += qv[e] * kf[e];
+          sd[d] = qsum(acc) * p.scale;
         }
       }
     }
-    // ---- scores of the absorbed tower's tokens against U -> pw[j][head] (this wave's LDS scratch); running max per head
-    float mx[2] = {-INFINITY, -INFINITY};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed
+    // ---- scores, joint softmax per head: lane (i, qd) holds tokens 4 qd + r of head i
+    const f32x4_t sacc = rows_dot(xs, u, i, qd);
+    float sc[4], mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < kMaxD; ++i) { mx[0] = fmaxf(mx[0], sd[i][0]); mx[1] = fmaxf(mx[1], sd[i][1]); }
+    for (int r = 0; r < 4; ++r) {
+      sc[r] = (valid >> r & 1u) ? (sacc[r] + cbh) * p.scale : -INFINITY;
+      mx = fmaxf(mx, sc[r]);
+    }
+    mx = qmax(mx);
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) mx = fmaxf(mx, sd[d]);
+    float l = 0.f, pd[kMaxD];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sc[r] = cmb_exp(sc[r] - mx); l += sc[r]; }   // exp(-inf) = 0
+    l = qsum(l);
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) { pd[d] = cmb_exp(sd[d] - mx); l += pd[d]; }
+    const float inv = 1.0f / l;
+    float m3v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sc[r] *= inv; m3v += sc[r]; }
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) pd[d] *= inv;
+    m3v = qsum(m3v);
     {
-      bf16x8_t u[kHeads][2];
-      const bf16_t* ur = p.U + qi * (int64_t)(kHeads * kC);
-#pragma unroll
-      for (int h = 0; h < kHeads; ++h) {
-        u[h][0] = *reinterpret_cast<const bf16x8_t*>(ur + h * kC + c0);
-        u[h][1] = *reinterpret_cast<const bf16x8_t*>(ur + h * kC + c1);
+      float* prow = p.P + (qi * kHeads + i) * kPStride;
+      *reinterpret_cast<f32x4_t*>(prow + 4 + 4 * qd) = f32x4_t{sc[0], sc[1], sc[2], sc[3]};
+      if (qd == 0) {
+        *reinterpret_cast<f32x4_t*>(prow) = f32x4_t{pd[0], pd[1], pd[2], pd[3]};
+        p.m3[qi * kHeads + i] = m3v;
       }
-      const float cb0 = p.cb[qi * kHeads + g], cb1 = p.cb[qi * kHeads + g + 8];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed (and U, the direct towers' rows)
-#pragma unroll 2
-      for (int j = 0; j < na; ++j) {
-        float s0 = -INFINITY, s1 = -INFINITY;
-        if (!(mka && mka[j] == 0)) {
-          const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + lane * 16);
-          const bf16x8_t x1 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + 1024 + lane * 16);
-          float part[kHeads];
-#pragma unroll
-          for (int h = 0; h < kHeads; ++h) part[h] = dot8(x1, u[h][1], dot8(x0, u[h][0], 0.f));
-          float a, bsum;
-          heads_reduce(part, lane, a, bsum);
-          s0 = (a + cb0) * p.scale;
-          s1 = (bsum + cb1) * p.scale;
-        }
-        mx[0] = fmaxf(mx[0], s0);
-        mx[1] = fmaxf(mx[1], s1);
-        if ((lane & 7) == 0) { pw[wave][j][g] = s0; pw[wave][j][g + 8] = s1; }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- joint softmax per head (every lane for its two heads; the absorbed scores come back from the scratch)
-    float l[2] = {0.f, 0.f}, m3v[2] = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < kMaxD; ++i)
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) { sd[i][cc] = cmb_exp(sd[i][cc] - mx[cc]); l[cc] += sd[i][cc]; }   // exp(-inf) = 0
-    for (int j = 0; j < na; ++j) {
-      l[0] += cmb_exp(pw[wave][j][g] - mx[0]);
-      l[1] += cmb_exp(pw[wave][j][g + 8] - mx[1]);
-    }
-    const float inv[2] = {1.0f / l[0], 1.0f / l[1]};
-    float* prow0 = p.P + (qi * kHeads + g) * (int64_t)p.nkeys;
-    float* prow1 = p.P + (qi * kHeads + g + 8) * (int64_t)p.nkeys;
-#pragma unroll
-    for (int i = 0; i < kMaxD; ++i) {
-      sd[i][0] *= inv[0];
-      sd[i][1] *= inv[1];
-      if (i < p.ntowers && (lane & 7) == 0) { prow0[i] = sd[i][0]; prow1[i] = sd[i][1]; }
-    }
-    // the absorbed tokens' probabilities: fp32 to P (the backward's input), bf16 pairs of consecutive tokens to pp (the
-    // coefficient operand of the token mix below; an odd window's last pair carries a zero)
-    for (int j = 0; j < na; j += 2) {
-      const bool two = j + 1 < na;
-      const float p0a = cmb_exp(pw[wave][j][g] - mx[0]) * inv[0], p1a = cmb_exp(pw[wave][j][g + 8] - mx[1]) * inv[1];
-      const float p0b = two ? cmb_exp(pw[wave][j + 1][g] - mx[0]) * inv[0] : 0.f;
-      const float p1b = two ? cmb_exp(pw[wave][j + 1][g + 8] - mx[1]) * inv[1] : 0.f;
-      m3v[0] += p0a + p0b;
-      m3v[1] += p1a + p1b;
-      if ((lane & 7) == 0) {
-        prow0[p.nd + j] = p0a;
-        prow1[p.nd + j] = p1a;
-        if (two) { prow0[p.nd + j + 1] = p0b; prow1[p.nd + j + 1] = p1b; }
-        pp[wave][j >> 1][g] = pack_bf16(p0a, p0b);
-        pp[wave][j >> 1][g + 8] = pack_bf16(p1a, p1b);
-      }
-    }
-    if ((lane & 7) == 0) {
-      p.m3[qi * kHeads + g] = m3v[0];
-      p.m3[qi * kHeads + g + 8] = m3v[1];
     }
     // ---- the direct towers' part of the output: sum_k p_k V_k
     {
-      float o0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      float o[16];
 #pragma unroll
-      for (int i = 0; i < kMaxD; ++i) {
-        if (i < p.ntowers && !(p.mask[i] && p.mask[i][qi] == 0)) {
-          const bf16_t* vr = p.kv[i] + qi * p.ldkv[i] + kC;
-          float v0[8], v1[8];
-          cvt8(*reinterpret_cast<const bf16x8_t*>(vr + c0), v0);
-          cvt8(*reinterpret_cast<const bf16x8_t*>(vr + c1), v1);
+      for (int e = 0; e < 16; ++e) o[e] = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { o0[e] += sd[i][0] * v0[e]; o1[e] += sd[i][1] * v1[e]; }
+      for (int d = 0; d < kMaxD; ++d) {
+        if (live[d]) {
+          float vf[16];
+          cvt16(vraw[d], vf);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[e] += pd[d] * vf[e];
         }
       }
-      bf16_t* orow = p.out + qi * p.ldo;
-      *reinterpret_cast<bf16x8_t*>(orow + c0) = cvt8_bf16(o0[0], o0[1], o0[2], o0[3], o0[4], o0[5], o0[6], o0[7]);
-      *reinterpret_cast<bf16x8_t*>(orow + c1) = cvt8_bf16(o1[0], o1[1], o1[2], o1[3], o1[4], o1[5], o1[6], o1[7]);
+      store16f(p.out + qi * p.ldo + ch, o);
     }
-    // ---- Xb[h][c] = sum_t p[t][h] xh_t[c]: one 512-channel half per pass (16 heads x 8 channels = 128 accumulators),
-    //      two tokens per v_dot2c (a masked token has p = 0 in every head)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      bf16_t* xo = p.xbar + qi * (int64_t)(kHeads * kC);
-#pragma unroll 1
-      for (int cc = 0; cc < 2; ++cc) {
-        float acc[kHeads][8];
-#pragma unroll
-        for (int h = 0; h < kHeads; ++h)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
-        const char* xc = xs + cc * 1024 + lane * 16;
-#pragma unroll 1
-        for (int j = 0; j < na; j += 2) {
-          const int j1 = j + 1 < na ? j + 1 : j;   // (coefficient 0)
-          const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(xc + j * 2048);
-          const u32x4_t xb2 = *reinterpret_cast<const u32x4_t*>(xc + j1 * 2048);
-          uint32_t pr[8];
-          interleave8(xa, xb2, pr);
-          mix16(pr, &pp[wave][j >> 1][0], acc);
-        }
-        const int cs = cc ? c1 : c0;
-#pragma unroll
-        for (int h = 0; h < kHeads; ++h)
-          *reinterpret_cast<bf16x8_t*>(xo + h * kC + cs) = cvt8_bf16(acc[h][0], acc[h][1], acc[h][2], acc[h][3], acc[h][4],
-                                                                      acc[h][5], acc[h][6], acc[h][7]);
-      }
-    }
+    // ---- Xb[h][c] = sum_t p[t][h] xh_t[c]: the probabilities are already the B operand
+    token_mix(xs, pack4_bf16(sc[0], sc[1], sc[2], sc[3]), p.xbar + qi * (int64_t)(kHeads * kC), i, qd);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this query is done before the next window's DMA
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sva_abs_bwd_kernel(const AbsParams p) {
+__global__ void __launch_bounds__(64) sva_abs_bwd_kernel(const AbsParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // per wave: the token window (LDS-DMA), P and dS (scale included) of the absorbed tokens for all heads
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 3;
-  char* xs = smem + wave * kWinBytes;
-  float (*pw)[kMaxKeys][kHeads] = reinterpret_cast<float (*)[kMaxKeys][kHeads]>(smem + 4 * kWinBytes);
-  float (*dw)[kMaxKeys][kHeads] = pw + 4;
-  // (P, dS) of every token and head as one bf16 pair; dS of consecutive tokens as one bf16 pair
-  uint32_t (*cf)[kMaxKeys][kHeads] = reinterpret_cast<uint32_t (*)[kMaxKeys][kHeads]>(smem + 4 * kWinBytes + 2 * kScratchF32);
-  uint32_t (*dsp)[kMaxKeys / 2][kHeads] =
-      reinterpret_cast<uint32_t (*)[kMaxKeys / 2][kHeads]>(smem + 4 * kWinBytes + 3 * kScratchF32);
+  const int lane = threadIdx.x, i = lane & 15, qd = lane >> 4;
+  char* xs = smem;
+  bf16_t* coef = reinterpret_cast<bf16_t*>(smem + kWinBytes);   // [t][32]: P[t][h], dS[t][h]
   const int64_t nq = (int64_t)p.B * p.qside * p.qside;
-  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
   const int na = p.ra * p.ra;
-  for (int64_t qi = wave_global; qi < nq; qi += nwaves) {
+  for (int64_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const int b = (int)(qi / (p.qside * p.qside));
     const int t = (int)(qi - (int64_t)b * p.qside * p.qside);
     const int qy = t / p.qside, qx = t - qy * p.qside;
-    const int c0 = lane * 8, c1 = 512 + lane * 8;
-    const float* prow0 = p.P + (qi * kHeads + g) * (int64_t)p.nkeys;
-    const float* prow1 = p.P + (qi * kHeads + g + 8) * (int64_t)p.nkeys;
-    const uint8_t* mka = p.mask_a ? p.mask_a + qi * na : nullptr;
     const int G = p.qside * p.ra;
     const int64_t xbase = (int64_t)b * G * G;
+    if (na < kMaxKeys) zero_tail_rows(xs, na, lane);   // (the window region is also the dX pass's operand stage)
+    // ---- everything the query reads from HBM is requested here, in one round trip
     stage_window(p, p.xhat + xbase * p.ldx, xs, na, t, qy, qx, lane);
-    float q0[8], q1[8], do0[8], do1[8];
-    cvt8(*reinterpret_cast<const bf16x8_t*>(p.q + qi * p.ldq + c0), q0);
-    cvt8(*reinterpret_cast<const bf16x8_t*>(p.q + qi * p.ldq + c1), q1);
-    cvt8(*reinterpret_cast<const bf16x8_t*>(p.dout + qi * p.lddo + c0), do0);
-    cvt8(*reinterpret_cast<const bf16x8_t*>(p.dout + qi * p.lddo + c1), do1);
-
-    // ---- dP of every key; D = sum_k P_k dP_k per head.  Direct towers: one key each (r == 1), dP = do . V
-    float pd[kMaxD][2], dsd[kMaxD][2];
-    float D[2] = {0.f, 0.f};
+    // dXb[h = i][32 s + 8 qd ...] and U[h = i][...]: B operands of the dP product, then the rows of W = (dXb; U)
+    bf16x8_t dxv[32], uv[32];
+    {
+      const bf16_t* dp = p.dxbar + qi * (int64_t)(kHeads * kC) + i * kC + qd * 8;
+      const bf16_t* up = p.U + qi * (int64_t)(kHeads * kC) + i * kC + qd * 8;
 #pragma unroll
-    for (int i = 0; i < kMaxD; ++i) {
-      pd[i][0] = pd[i][1] = dsd[i][0] = dsd[i][1] = 0.f;
-      if (i < p.ntowers && !(p.mask[i] && p.mask[i][qi] == 0)) {
-        pd[i][0] = prow0[i];
-        pd[i][1] = prow1[i];
-        const bf16_t* vr = p.kv[i] + qi * p.ldkv[i] + kC;
-        float v0[8], v1[8];
-        cvt8(*reinterpret_cast<const bf16x8_t*>(vr + c0), v0);
-        cvt8(*reinterpret_cast<const bf16x8_t*>(vr + c1), v1);
-        float s0 = 0.f, s1 = 0.f;
+      for (int s = 0; s < 32; ++s) dxv[s] = *reinterpret_cast<const bf16x8_t*>(dp + s * 32);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s0 += do0[e] * v0[e]; s1 += do1[e] * v1[e]; }
-        dsd[i][0] = head_sum8(s0);
-        dsd[i][1] = head_sum8(s1);
-        D[0] += pd[i][0] * dsd[i][0];
-        D[1] += pd[i][1] * dsd[i][1];
+      for (int s = 0; s < 32; ++s) uv[s] = *reinterpret_cast<const bf16x8_t*>(up + s * 32);
+    }
+    const int ch = i * kHd + qd * 16;
+    const Raw16 qraw = load16(p.q + qi * p.ldq + ch), doraw = load16(p.dout + qi * p.lddo + ch);
+    Raw16 kraw[kMaxD], vraw[kMaxD];
+    bool live[kMaxD];
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) {
+      live[d] = d < p.ntowers && !(p.mask[d] && p.mask[d][qi] == 0);
+      if (live[d]) {
+        const bf16_t* kr = p.kv[d] + qi * p.ldkv[d] + ch;
+        kraw[d] = load16(kr);
+        vraw[d] = load16(kr + kC);
       }
     }
-    {  // absorbed tokens: dP[t][h] = dXb[h] . xh_t + dm3[h]  ->  pw = P, dw = dP (this wave's LDS scratch)
-      bf16x8_t dx[kHeads][2];
-      const bf16_t* dr = p.dxbar + qi * (int64_t)(kHeads * kC);
+    const float* prow = p.P + (qi * kHeads + i) * kPStride;
+    const f32x4_t pa = *reinterpret_cast<const f32x4_t*>(prow + 4 + 4 * qd);
+    const f32x4_t pdv = *reinterpret_cast<const f32x4_t*>(prow);
+    const float dm3h = p.dm3[qi * kHeads + i];
+    float qv[16], dov[16];
+    cvt16(qraw, qv);
+    cvt16(doraw, dov);
+    // ---- dP of every key; D = sum_k P_k dP_k per head.  Direct towers: dP = do . V
+    float pd[kMaxD], dsd[kMaxD];
+    float D = 0.f;
 #pragma unroll
-      for (int h = 0; h < kHeads; ++h) {
-        dx[h][0] = *reinterpret_cast<const bf16x8_t*>(dr + h * kC + c0);
-        dx[h][1] = *reinterpret_cast<const bf16x8_t*>(dr + h * kC + c1);
-      }
-      const float dm0 = p.dm3[qi * kHeads + g], dm1 = p.dm3[qi * kHeads + g + 8];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed
-#pragma unroll 2
-      for (int j = 0; j < na; ++j) {
-        float p0 = 0.f, p1 = 0.f, d0 = 0.f, d1 = 0.f;
-        if (!(mka && mka[j] == 0)) {
-          p0 = prow0[p.nd + j];
-          p1 = prow1[p.nd + j];
-          const bf16x8_t x0 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + lane * 16);
-          const bf16x8_t x1 = *reinterpret_cast<const bf16x8_t*>(xs + j * 2048 + 1024 + lane * 16);
-          float part[kHeads];
+    for (int d = 0; d < kMaxD; ++d) {
+      pd[d] = dsd[d] = 0.f;
+      if (live[d]) {
+        pd[d] = pdv[d];
+        float vf[16];
+        cvt16(vraw[d], vf);
+        float acc = 0.f;
 #pragma unroll
-          for (int h = 0; h < kHeads; ++h) part[h] = dot8(x1, dx[h][1], dot8(x0, dx[h][0], 0.f));
-          float a, bsum;
-          heads_reduce(part, lane, a, bsum);
-          d0 = a + dm0;
-          d1 = bsum + dm1;
-          D[0] += p0 * d0;
-          D[1] += p1 * d1;
-        }
-        if ((lane & 7) == 0) {
-          pw[wave][j][g] = p0;
-          pw[wave][j][g + 8] = p1;
-          dw[wave][j][g] = d0;
-          dw[wave][j][g + 8] = d1;
-        }
+        for (int e = 0; e < 16; ++e) acc += dov[e] * vf[e];
+        dsd[d] = qsum(acc);
+        D += pd[d] * dsd[d];
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- dS (scale included); d(cb); the coefficient pairs of the two token mixes below
-    float dcb[2] = {0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed
+    const f32x4_t dpa = rows_dot(xs, dxv, i, qd);        // dP[t][h] - dm3[h]  (a masked or absent token has P = 0)
+    {
+      float part = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxD; ++i) {
-      dsd[i][0] = pd[i][0] * (dsd[i][0] - D[0]) * p.scale;
-      dsd[i][1] = pd[i][1] * (dsd[i][1] - D[1]) * p.scale;
+      for (int r = 0; r < 4; ++r) part += pa[r] * (dpa[r] + dm3h);
+      D += qsum(part);
     }
-    for (int j = 0; j < na; j += 2) {
-      const bool two = j + 1 < na;
-      const float p0a = pw[wave][j][g], p1a = pw[wave][j][g + 8];
-      const float s0a = p0a * (dw[wave][j][g] - D[0]) * p.scale, s1a = p1a * (dw[wave][j][g + 8] - D[1]) * p.scale;
-      float p0b = 0.f, p1b = 0.f, s0b = 0.f, s1b = 0.f;
-      if (two) {
-        p0b = pw[wave][j + 1][g];
-        p1b = pw[wave][j + 1][g + 8];
-        s0b = p0b * (dw[wave][j + 1][g] - D[0]) * p.scale;
-        s1b = p1b * (dw[wave][j + 1][g + 8] - D[1]) * p.scale;
-      }
-      dcb[0] += s0a + s0b;
-      dcb[1] += s1a + s1b;
-      if ((lane & 7) == 0) {
-        cf[wave][j][g] = pack_bf16(p0a, s0a);
-        cf[wave][j][g + 8] = pack_bf16(p1a, s1a);
-        if (two) {
-          cf[wave][j + 1][g] = pack_bf16(p0b, s0b);
-          cf[wave][j + 1][g + 8] = pack_bf16(p1b, s1b);
-        }
-        dsp[wave][j >> 1][g] = pack_bf16(s0a, s0b);
-        dsp[wave][j >> 1][g + 8] = pack_bf16(s1a, s1b);
-      }
-    }
-    if ((lane & 7) == 0) {
-      p.dcb[qi * kHeads + g] = dcb[0];
-      p.dcb[qi * kHeads + g + 8] = dcb[1];
+    // ---- dS (scale included); d(cb)
+    float ds[4], dcb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ds[r] = pa[r] * (dpa[r] + dm3h - D) * p.scale; dcb += ds[r]; }
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) dsd[d] = pd[d] * (dsd[d] - D) * p.scale;
+    dcb = qsum(dcb);
+    if (qd == 0) p.dcb[qi * kHeads + i] = dcb;
+    // (P | dS)[t][k] for the dX product: this lane's tokens 4 qd + r, columns i and 16 + i
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      coef[(4 * qd + r) * 32 + i] = (bf16_t)pa[r];
+      coef[(4 * qd + r) * 32 + 16 + i] = (bf16_t)ds[r];
     }
     // ---- direct towers: dq += dS K, dK = dS q, dV = P do
     {
-      float dq0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dq1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      float dq[16];
 #pragma unroll
-      for (int i = 0; i < kMaxD; ++i) {
-        if (i < p.ntowers) {
-          bf16_t* dkr = p.dkv[i] + qi * p.ldkv[i];
-          float dk0[8], dk1[8], dv0[8], dv1[8];
-          if (p.mask[i] && p.mask[i][qi] == 0) {
+      for (int e = 0; e < 16; ++e) dq[e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { dk0[e] = dk1[e] = dv0[e] = dv1[e] = 0.f; }
+      for (int d = 0; d < kMaxD; ++d) {
+        if (d < p.ntowers) {
+          bf16_t* dkr = p.dkv[d] + qi * p.ldkv[d] + ch;
+          float dk[16], dv[16];
+          if (!live[d]) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dk[e] = dv[e] = 0.f;
           } else {
-            const bf16_t* kr = p.kv[i] + qi * p.ldkv[i];
-            float k0[8], k1[8];
-            cvt8(*reinterpret_cast<const bf16x8_t*>(kr + c0), k0);
-            cvt8(*reinterpret_cast<const bf16x8_t*>(kr + c1), k1);
+            float kf[16];
+            cvt16(kraw[d], kf);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              dq0[e] += dsd[i][0] * k0[e];
-              dq1[e] += dsd[i][1] * k1[e];
-              dk0[e] = dsd[i][0] * q0[e];
-              dk1[e] = dsd[i][1] * q1[e];
-              dv0[e] = pd[i][0] * do0[e];
-              dv1[e] = pd[i][1] * do1[e];
+            for (int e = 0; e < 16; ++e) {
+              dq[e] += dsd[d] * kf[e];
+              dk[e] = dsd[d] * qv[e];
+              dv[e] = pd[d] * dov[e];
             }
           }
-          *reinterpret_cast<bf16x8_t*>(dkr + c0) = cvt8_bf16(dk0[0], dk0[1], dk0[2], dk0[3], dk0[4], dk0[5], dk0[6], dk0[7]);
-          *reinterpret_cast<bf16x8_t*>(dkr + c1) = cvt8_bf16(dk1[0], dk1[1], dk1[2], dk1[3], dk1[4], dk1[5], dk1[6], dk1[7]);
-          *reinterpret_cast<bf16x8_t*>(dkr + kC + c0) = cvt8_bf16(dv0[0], dv0[1], dv0[2], dv0[3], dv0[4], dv0[5], dv0[6], dv0[7]);
-          *reinterpret_cast<bf16x8_t*>(dkr + kC + c1) = cvt8_bf16(dv1[0], dv1[1], dv1[2], dv1[3], dv1[4], dv1[5], dv1[6], dv1[7]);
+          store16f(dkr, dk);
+          store16f(dkr + kC, dv);
         }
       }
-      bf16_t* dqr = p.dq + qi * p.lddq;
-      *reinterpret_cast<bf16x8_t*>(dqr + c0) = cvt8_bf16(dq0[0], dq0[1], dq0[2], dq0[3], dq0[4], dq0[5], dq0[6], dq0[7]);
-      *reinterpret_cast<bf16x8_t*>(dqr + c1) = cvt8_bf16(dq1[0], dq1[1], dq1[2], dq1[3], dq1[4], dq1[5], dq1[6], dq1[7]);
+      store16f(p.dq + qi * p.lddq + ch, dq);
     }
-    // ---- absorbed tower, one 512-channel half per pass, two terms per v_dot2c:
-    //      d(xh_t)[c] = sum_h P[t][h] dXb[h][c] + dS[t][h] U[h][c]     ((dXb, U) element pairs x (P, dS) pairs)
-    //      dU[h][c]   = sum_t dS[t][h] xh_t[c]                          (token-pair element pairs x dS pairs)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- dU[h][c] = sum_t dS[t][h] xh_t[c]
+    token_mix(xs, pack4_bf16(ds[0], ds[1], ds[2], ds[3]), p.dU + qi * (int64_t)(kHeads * kC), i, qd);
+    // ---- d(xh_t)[c] = sum_h P[t][h] dXb[h][c] + dS[t][h] U[h][c]: one 512-channel half of W = (dXb; U) [32][512] at a time
+    //      in the window's LDS region, written from the registers that fed the dP product (dXb) and were loaded beside
+    //      them (U): no second trip to memory.  W^T by transposing reads, Coef^T from the scratch.
     {
-      bf16_t* dxb = p.dxhat + xbase * p.lddx;
-      const bf16_t* ur = p.U + qi * (int64_t)(kHeads * kC);
-      const bf16_t* dr = p.dxbar + qi * (int64_t)(kHeads * kC);
-      bf16_t* duo = p.dU + qi * (int64_t)(kHeads * kC);
-#pragma unroll 1
-      for (int cc = 0; cc < 2; ++cc) {
-        const int cs = cc ? c1 : c0;
-        {
-          uint32_t pr[kHeads][8];
+      const bf16x8_t cf = *reinterpret_cast<const bf16x8_t*>(coef + i * 32 + qd * 8);   // Coef[k = 8 qd + j][t = i]
+      // transposing read: rows rw and rw + 4 of W (k = 8 qd + j), piece i % 4; write: rows i and 16 + i
+      const int rw = 8 * qd + (i >> 2);
+      const char* wr = xs + rw * 1024 + (i & 3) * 16;
+      char* ww = xs + i * 1024 + qd * 16;
+      bf16_t* dxrow = p.dxhat + (xbase + token_row(p, t, qy, qx, p.ra, i < na ? i : 0)) * p.lddx + qd * 8;
 #pragma unroll
-          for (int h = 0; h < kHeads; ++h)
-            interleave8(*reinterpret_cast<const u32x4_t*>(dr + h * kC + cs), *reinterpret_cast<const u32x4_t*>(ur + h * kC + cs),
-                        pr[h]);
-#pragma unroll 1
-          for (int j = 0; j < na; ++j) {   // (a masked token has P = dS = 0 in every head: its gradient row is zero)
-            float dx[2][8];
+      for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dx[0][e] = dx[1][e] = 0.f;
-#pragma unroll
-            for (int hq = 0; hq < 4; ++hq) {
-              const u32x4_t c4 = *reinterpret_cast<const u32x4_t*>(&cf[wave][j][hq * 4]);
-#pragma unroll
-              for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dx[hh & 1][e] = dot2(pr[hq * 4 + hh][e], c4[hh], dx[hh & 1][e]);
-            }
-            const int64_t row = token_row(p, t, qy, qx, p.ra, j);
-            *reinterpret_cast<bf16x8_t*>(dxb + row * p.lddx + cs) =
-                cvt8_bf16(dx[0][0] + dx[1][0], dx[0][1] + dx[1][1], dx[0][2] + dx[1][2], dx[0][3] + dx[1][3],
-                          dx[0][4] + dx[1][4], dx[0][5] + dx[1][5], dx[0][6] + dx[1][6], dx[0][7] + dx[1][7]);
-          }
+        for (int s = 0; s < 16; ++s) {
+          *reinterpret_cast<bf16x8_t*>(ww + ((s ^ i) << 6)) = dxv[half * 16 + s];
+          *reinterpret_cast<bf16x8_t*>(ww + 16 * 1024 + ((s ^ i) << 6)) = uv[half * 16 + s];
         }
-        {
-          float du[kHeads][8];
+#pragma unroll 2
+        for (int cg = 0; cg < 16; ++cg) {
+          f32x4_t dd[2];
 #pragma unroll
-          for (int h = 0; h < kHeads; ++h)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) du[h][e] = 0.f;
-          const char* xc = xs + cc * 1024 + lane * 16;
-#pragma unroll 1
-          for (int j = 0; j < na; j += 2) {
-            const int j1 = j + 1 < na ? j + 1 : j;   // (coefficient 0)
-            const u32x4_t xa = *reinterpret_cast<const u32x4_t*>(xc + j * 2048);
-            const u32x4_t xb2 = *reinterpret_cast<const u32x4_t*>(xc + j1 * 2048);
-            uint32_t xp[8];
-            interleave8(xa, xb2, xp);
-            mix16(xp, &dsp[wave][j >> 1][0], du);
+          for (int T = 0; T < 2; ++T) {
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(wr + ((cg ^ (rw & 15)) << 6) + T * 8));
+            const s16x4_t hi =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(wr + 4 * 1024 + ((cg ^ ((rw + 4) & 15)) << 6) + T * 8));
+            const s16x8_t a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            dd[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), cf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0,
+                                                            0, 0);
           }
-#pragma unroll
-          for (int h = 0; h < kHeads; ++h)
-            *reinterpret_cast<bf16x8_t*>(duo + h * kC + cs) =
-                cvt8_bf16(du[h][0], du[h][1], du[h][2], du[h][3], du[h][4], du[h][5], du[h][6], du[h][7]);
+          if (i < na)
+            *reinterpret_cast<bf16x8_t*>(dxrow + half * 512 + cg * 32) =
+                cvt8_bf16(dd[0][0], dd[0][1], dd[0][2], dd[0][3], dd[1][0], dd[1][1], dd[1][2], dd[1][3]);
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of this query is done before the next window's DMA
-    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS access of this query is done before the next window's DMA
   }
 }
 
@@ -602,7 +462,6 @@ int fill(const cmb_sva_abs_desc* d, AbsParams& p, bool bwd) {
   if (d->ntowers < 0 || d->ntowers > kMaxD || d->ra <= 0 || d->ra * d->ra > kMaxKeys) return CMB_ERR_SHAPE;
   p.B = d->B; p.qside = d->qside; p.ntowers = d->ntowers; p.window_major = d->window_major;
   p.q = (const bf16_t*)d->q; p.ldq = d->ldq;
-  p.nd = 0;
   for (int i = 0; i < d->ntowers; ++i) {
     if (!d->kv[i]) return CMB_ERR_BAD_ARG;
     if (d->r[i] != 1) return CMB_ERR_SHAPE;   // directly projected towers: one key per query
@@ -610,7 +469,6 @@ int fill(const cmb_sva_abs_desc* d, AbsParams& p, bool bwd) {
     p.mask[i] = d->mask[i];
     p.dkv[i] = (bf16_t*)d->dkv[i];
     if (bwd && !d->dkv[i]) return CMB_ERR_BAD_ARG;
-    p.nd += d->r[i] * d->r[i];
   }
   p.ra = d->ra;
   p.xhat = (const bf16_t*)d->xhat; p.ldx = d->ldx;
@@ -618,7 +476,6 @@ int fill(const cmb_sva_abs_desc* d, AbsParams& p, bool bwd) {
   p.U = (const bf16_t*)d->U; p.cb = d->cb;
   p.out = (bf16_t*)d->out; p.ldo = d->ldo;
   p.xbar = (bf16_t*)d->xbar; p.m3 = d->m3; p.P = d->P;
-  p.nkeys = p.nd + d->ra * d->ra;
   p.dout = (const bf16_t*)d->dout; p.lddo = d->lddo;
   p.dxbar = (const bf16_t*)d->dxbar; p.dm3 = d->dm3;
   p.dq = (bf16_t*)d->dq; p.lddq = d->lddq;
@@ -637,8 +494,7 @@ extern "C" int cmb_sva_abs_fwd(const cmb_sva_abs_desc* d, void* stream) {
   if (rc != CMB_OK) return rc;
   const int64_t nq = (int64_t)p.B * p.qside * p.qside;
   if (nq == 0) return CMB_OK;
-  int64_t blocks = (nq + 3) / 4;
-  if (blocks > 16384) blocks = 16384;
+  const int64_t blocks = nq < (1 << 20) ? nq : (1 << 20);
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sva_abs_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -646,7 +502,7 @@ extern "C" int cmb_sva_abs_fwd(const cmb_sva_abs_desc* d, void* stream) {
       return CMB_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(sva_abs_fwd_kernel, dim3((unsigned)blocks), dim3(256), kSmemFwd, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(sva_abs_fwd_kernel, dim3((unsigned)blocks), dim3(64), kSmemFwd, (hipStream_t)stream, p);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }
@@ -657,8 +513,7 @@ extern "C" int cmb_sva_abs_bwd(const cmb_sva_abs_desc* d, void* stream) {
   if (rc != CMB_OK) return rc;
   const int64_t nq = (int64_t)p.B * p.qside * p.qside;
   if (nq == 0) return CMB_OK;
-  int64_t blocks = (nq + 3) / 4;
-  if (blocks > 16384) blocks = 16384;
+  const int64_t blocks = nq < (1 << 20) ? nq : (1 << 20);
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sva_abs_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -666,7 +521,7 @@ extern "C" int cmb_sva_abs_bwd(const cmb_sva_abs_desc* d, void* stream) {
       return CMB_ERR_LAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(sva_abs_bwd_kernel, dim3((unsigned)blocks), dim3(256), kSmemBwd, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(sva_abs_bwd_kernel, dim3((unsigned)blocks), dim3(64), kSmemBwd, (hipStream_t)stream, p);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

@@ -114,6 +114,7 @@ SIGNATURES = {
     "cmb_version": (C.c_char_p, []),
     "cmb_abi_version": (C.c_int, []),
     "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
+    "cmb_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), _p]),
     "cmb_gemm_tile": (C.c_int, [C.c_int, _i64, _i64, _i32, _i32]),
     "cmb_gemm_last_kernel": (C.c_int, []),
     "cmb_gemm_policy_set": (C.c_int, [_i64, _i64, _i64, _i32, _i32]),

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -390,6 +391,46 @@ def k_transpose(x: torch.Tensor, r_pad: Optional[int] = None) -> torch.Tensor:
     return out
 
 
+def k_gemm_tn(at: torch.Tensor, bt: torch.Tensor, *, out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32,
+              split_k: int = 1, alpha: float = 1.0, beta: float = 0.0, M: Optional[int] = None, N: Optional[int] = None,
+              batch: int = 1, a_bs: int = 0, b_bs: int = 0, c_bs: int = 0, ldc: Optional[int] = None) -> torch.Tensor:
+    """C[M,N] = alpha * At[K,M]^T @ Bt[K,N] (+ beta C) on cmb_gemm_tn: both operands row-major over the K contraction rows,
+    bf16, any K.  ``at`` [K, >=M] / ``bt`` [K, >=N] (row strides taken from the tensors); with ``batch`` > 1 problem z
+    reads columns from a_bs*z / b_bs*z on and writes C + c_bs*z (elements).  The weight gradient dW = g^T x without
+    transposed copies of g and x."""
+    L.require_gpu(at, bt, out)
+    if at.dtype != torch.bfloat16 or bt.dtype != torch.bfloat16 or at.dim() != 2 or bt.dim() != 2:
+        raise L.CambrianAmdError("gemm_tn operands must be 2-D bf16")
+    if at.stride(1) != 1 or bt.stride(1) != 1 or at.shape[0] != bt.shape[0]:
+        raise L.CambrianAmdError("gemm_tn operands must be row-major with equal row counts")
+    K = at.shape[0]
+    M = at.shape[1] if M is None else M
+    N = bt.shape[1] if N is None else N
+    if out is None:
+        if batch > 1:
+            raise L.CambrianAmdError("gemm_tn: a batched launch needs the caller's output tensor")
+        out = torch.empty((M, N), dtype=out_dtype, device=at.device)
+    d = GemmDesc()
+    d.dtype, d.out_dtype = L.dtype_code(at.dtype), L.dtype_code(out.dtype)
+    d.M, d.N, d.K = M, N, K
+    d.A, d.a_map = at.data_ptr(), L.identity_map(at.stride(0))
+    d.B, d.ldb = bt.data_ptr(), bt.stride(0)
+    d.C, d.c_map = out.data_ptr(), L.identity_map(ldc if ldc is not None else out.stride(0))
+    d.bias = d.colscale = d.residual = d.pre_out = None
+    d.r_map = d.p_map = L.identity_map(0)
+    d.act, d.alpha, d.beta, d.split_k, d.tile_hint = L.ACT_NONE, alpha, beta, split_k, 0
+    ws = None
+    if split_k > 1:
+        ws = torch.empty((split_k * max(batch, 1) * M * N,), dtype=torch.float32, device=at.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    else:
+        d.workspace, d.workspace_bytes = None, 0
+    d.batch, d.a_batch_stride, d.b_batch_stride, d.c_batch_stride = batch, a_bs, b_bs, c_bs
+    rc = L.load().cmb_gemm_tn(C.byref(d), L.stream_ptr(at.device))
+    L.check(rc, f"cmb_gemm_tn(M={M}, N={N}, K={K}, batch={batch})")
+    return out
+
+
 def k_colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     L.require_gpu(x)
     R, Cc = x.shape
@@ -507,6 +548,18 @@ def k_sva_attn_bwd(dout, q, kvs, masks, r_list, out, lse, B, qside, heads, hd, w
 # ================================================================================================
 # autograd: linear
 # ================================================================================================
+# CAMBRIAN_AMD_TN_WGRAD=0: weight gradients through transposed copies + the NT kernels (A/B runs, tests of the old path)
+TN_WGRAD = os.environ.get("CAMBRIAN_AMD_TN_WGRAD", "1") != "0"
+
+
+def _tn_wgrad_wins(rows: int, n_out: int, k_in: int) -> bool:
+    """Where dW = g^T x on cmb_gemm_tn beats transposed copies + the 256-tile NT kernels (tools/bench_tn.py,
+    profiles/r03c_wgrad_tn_vs_nt.md): weight matrices up to 2048 x 1024 at the query-side row counts.  The 128 x 128 TN tile
+    runs 350-900 TFLOP/s; the large products (the ConvNeXt-side projector at 147456 rows, the 4096-wide mm_projector)
+    stay on the 4-wave NT kernel at 1.0-1.25 PFLOP/s even with their transposes paid."""
+    return n_out * k_in <= 2048 * 1024 and rows <= 32768
+
+
 def _wgrad_splits(n_out: int, k_in: int, m_pad: int, kstep: int) -> int:
     tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
     want = max(1, 768 // tiles)
@@ -587,10 +640,14 @@ class LinearFn(torch.autograd.Function):
             else:
                 dx = k_gemm(g, w_t)
         if need_w:
-            m_pad = pad_to(M, ks)
-            g_t = k_transpose(g, m_pad)  # [N, M_pad]
-            x_t = k_transpose(x, m_pad)  # [K, M_pad]
-            dw = k_gemm(g_t, x_t, out_dtype=torch.float32, split_k=_wgrad_splits(N, K, m_pad, ks))
+            if dt == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and x.stride(1) == 1 and TN_WGRAD and _tn_wgrad_wins(M, N, K):
+                # dW = g^T x with g and x as they lie (cmb_gemm_tn: transposing LDS reads, rows beyond M contribute zero)
+                dw = k_gemm_tn(g, x, split_k=_wgrad_splits(N, K, pad_to(M, 64), 64))
+            else:  # fp32 parity path / odd widths: transposed copies for the NT kernel
+                m_pad = pad_to(M, ks)
+                g_t = k_transpose(g, m_pad)  # [N, M_pad]
+                x_t = k_transpose(x, m_pad)  # [K, M_pad]
+                dw = k_gemm(g_t, x_t, out_dtype=torch.float32, split_k=_wgrad_splits(N, K, m_pad, ks))
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         if need_b and ctx.has_bias:
@@ -819,7 +876,7 @@ class HeadExpandFn(torch.autograd.Function):
     """U[q, h, :] = x[q, h*hd:(h+1)*hd] @ W[h*hd:(h+1)*hd, :]   (x [Bq, H*hd], W [H*hd, Cin] -> U [Bq, H, Cin]): the K
     projection of the windowed tower applied to the QUERY (U = W_k,h^T q_h) and, with x = d(o), the V projection's backward
     (d Xb = W_v,h^T d o_h).  H GEMMs with K = hd = 64 in one batched launch; backward: dx_h = dU_h W_h^T (N = 64),
-    dW_h = x_h^T dU_h (M = 64, contraction over the queries: both operands transposed first)."""
+    dW_h = x_h^T dU_h (M = 64, contraction over the queries: cmb_gemm_tn, batched)."""
 
     @staticmethod
     def forward(ctx, x, w, heads: int):
@@ -847,12 +904,9 @@ class HeadExpandFn(torch.autograd.Function):
             k_gemm_batched(dU, w_c, dx, batch=heads, M=Bq, N=hd, K=Cin, lda=heads * Cin, ldb=Cin, ldc=C, a_bs=Cin,
                            b_bs=hd * Cin, c_bs=hd)
         if ctx.needs_input_grad[1]:
-            bqp = pad_to(Bq, 64)
-            x_t = k_transpose(x, bqp)                                # [C, Bqp]
-            du_t = k_transpose(dU.view(Bq, heads * Cin), bqp)        # [H*Cin, Bqp]
             dw = torch.empty((C, Cin), dtype=torch.float32, device=x.device)
-            k_gemm_batched(x_t, du_t, dw, batch=heads, M=hd, N=Cin, K=bqp, lda=bqp, ldb=bqp, ldc=Cin, a_bs=hd * bqp,
-                           b_bs=Cin * bqp, c_bs=hd * Cin)
+            k_gemm_tn(x, dU.view(Bq, heads * Cin), out=dw, M=hd, N=Cin, batch=heads, a_bs=hd, b_bs=Cin, c_bs=hd * Cin, ldc=Cin,
+                      split_k=_wgrad_splits(C, Cin, pad_to(Bq, 64), 64))
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         return dx, dw, None
@@ -892,12 +946,9 @@ class HeadContractFn(torch.autograd.Function):
             k_gemm_batched(dy, w_t, dxb, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=C, ldc=heads * Cin, a_bs=hd, b_bs=hd,
                            c_bs=Cin)
         if ctx.needs_input_grad[1]:
-            bqp = pad_to(Bq, 64)
-            dy_t = k_transpose(dy, bqp)                              # [C, Bqp]
-            xb_t = k_transpose(xb.view(Bq, heads * Cin), bqp)        # [H*Cin, Bqp]
             dw = torch.empty((C, Cin), dtype=torch.float32, device=xb.device)
-            k_gemm_batched(dy_t, xb_t, dw, batch=heads, M=hd, N=Cin, K=bqp, lda=bqp, ldb=bqp, ldc=Cin, a_bs=hd * bqp,
-                           b_bs=Cin * bqp, c_bs=hd * Cin)
+            k_gemm_tn(dy, xb.view(Bq, heads * Cin), out=dw, M=hd, N=Cin, batch=heads, a_bs=hd, b_bs=Cin, c_bs=hd * Cin, ldc=Cin,
+                      split_k=_wgrad_splits(C, Cin, pad_to(Bq, 64), 64))
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         return dxb, dw, None
@@ -930,11 +981,10 @@ class SvaAbsorbedFn(torch.autograd.Function):
             raise L.CambrianAmdError("absorbed SVA attention: xhat must be [B*(qside*ra)^2, 1024]")
         kvs = [kv if kv.stride(1) == 1 else kv.contiguous() for kv in kvs]
         Uc, cbc = U.contiguous(), cb.to(torch.float32).contiguous()
-        nkeys = len(kvs) + ra * ra
         out = torch.empty((Bq, 1024), dtype=q.dtype, device=q.device)
         xbar = torch.empty((Bq, 16, 1024), dtype=q.dtype, device=q.device)
         m3 = torch.empty((Bq, 16), dtype=torch.float32, device=q.device)
-        P = torch.empty((Bq, 16, nkeys), dtype=torch.float32, device=q.device)
+        P = torch.empty((Bq, 16, 20), dtype=torch.float32, device=q.device)   # [0, 4) direct keys, [4, 20) window tokens
         d = L.SvaAbsDesc()
         _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, Uc, cbc, B, qside, window_major)
         d.out, d.ldo, d.xbar, d.m3, d.P = out.data_ptr(), out.stride(0), xbar.data_ptr(), m3.data_ptr(), P.data_ptr()

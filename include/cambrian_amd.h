@@ -110,6 +110,15 @@ typedef struct cmb_gemm_desc {
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);
+/* C[M,N] = alpha * At[K,M]^T * Bt[K,N] (+ beta * C): the weight-gradient product dW = g^T x of every trainable linear of
+ * the path (autograd's addmm on a transposed view in the reference: the SVA projections vision_sampler.py:159-189, the
+ * projectors cambrian_arch.py:49-56), with BOTH operands row-major over the contraction rows as the activations lie in
+ * memory — no transposed copies.  Same descriptor as cmb_gemm, read as: A = At (row stride a_map.s2, a_map.n1 == 0),
+ * B = Bt (row stride ldb), K = contraction rows (any count: rows beyond K contribute zero), M, N multiples of 8;
+ * dtype CMB_BF16, out_dtype CMB_F32 | CMB_BF16; split_k / workspace and batch / *_batch_stride as cmb_gemm (both together
+ * when the batch's results are contiguous: c_batch_stride == M * N, row stride N; workspace split_k * batch * M * N * 4 bytes);
+ * bias, colscale, residual, pre_out, act must be unset.  cmb_gemm_last_kernel() reports 1281. */
+int cmb_gemm_tn(const cmb_gemm_desc* d, void* stream);
 /* Row-wise fp8 quantisation for cmb_gemm(CMB_FP8_E4M3): for every row r of x [rows, K] (dtype CMB_BF16 | CMB_F32, row
  * stride ldx elements):  amax = max|x[r,:]|;  s = 448 / amax (1 if amax == 0);
  * q[r,k] = e4m3fn_rne(clamp(x[r,k] * s, -448, 448));  inv_scale[r] = amax / 448 (1 if amax == 0).
@@ -121,7 +130,7 @@ int cmb_quantize_fp8_rows(int dtype, const void* x, int64_t ldx, int64_t rows, i
 int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint);
 /* which kernel the calling thread's most recent cmb_gemm launched (0 before the first): 128 = 128x128 tile kernel,
  * 256 = 8-wave 256x256 kernel (gemm256.hip), 2590 = 4-wave register-buffered 256x256 kernel (gemm_nt_p5_kernel,
- * gemm_p5.hip).  For labelling profiles and rooflines per kernel. */
+ * gemm_p5.hip), 1281 = cmb_gemm_tn's 128x128 kernel (gemm_tn.hip).  For labelling profiles and rooflines per kernel. */
 int cmb_gemm_last_kernel(void);
 /* Per-shape dispatch policy: bf16 launches of exactly (M, N, K, act) without a tile_hint and without split-K take
  * `kernel` (128 | 2560 = 8-wave 256x256 | 2590 = 4-wave 256x256; 0 removes the entry) instead of the built-in cost
@@ -241,7 +250,8 @@ int cmb_sva_attn_bwd(const cmb_sva_desc* d, void* stream);
  *   xhat : [B * (qside*ra)^2, 1024]  the LayerNorm-normalised tokens (affines folded into W_k, W_v, b_k, b_v)
  *   U    : [Bq, 16, 1024]            U[q,h,:] = W_k,h^T q_h           (cmb_gemm, batch = 16, K = 64)
  *   cb   : fp32 [Bq, 16]             cb[q,h] = b_k,h . q_h
- * and receives, besides the joint-softmax probabilities P (fp32 [Bq, 16, ntowers + ra*ra], saved for the backward),
+ * and receives, besides the joint-softmax probabilities P (fp32 [Bq, 16, 20]: columns [0, 4) the direct towers' keys,
+ * [4, 20) the absorbed tower's window tokens, zero where absent or masked; saved for the backward),
  *   out  : [Bq, 1024]   sum over the DIRECT towers' keys of p * V           (kv / mask / r as in cmb_sva_desc; r_i == 1)
  *   xbar : [Bq, 16, 1024]  Xb[q,h,:] = sum_t p[q,h,t] xhat_t     -> the absorbed tower's output is W_v,h Xb + m3 b_v,h
  *   m3   : fp32 [Bq, 16]   sum_t p[q,h,t] over the absorbed tower's tokens
