@@ -317,6 +317,7 @@ PARITY = {
 }
 
 
+ABSORB_KV_ON = False   # set in main(): whether the SVA layers take the absorbed K / V path (bf16 training default)
 PMC_FILES = {2590: "r03_pmc_gemm_p5.json", 256: "r03_pmc_gemm_8wave.json"}   # cmb_gemm_last_kernel id -> profiles/ file
 
 
@@ -398,7 +399,10 @@ def main():
     if world > 1:
         dist.barrier()
     from cambrian_amd import ops
+    from cambrian_amd.model import vision_sampler as _vs
     from cambrian_amd.train.data_layout import synthetic_batch
+    global ABSORB_KV_ON
+    ABSORB_KV_ON = bool(_vs.ABSORB_KV)
 
     model, cfg = build_model(dev, args.llm_layers, args.preset)
     cfg.fp8_projections = bool(args.fp8_projections)
@@ -649,7 +653,12 @@ def main():
                     "achieved": region_tflop / (region_ms * 1e-3) if region_ms > 0 else 0.0, "unit": "TFLOP/s",
                     "frac": region_tflop / (region_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS if region_ms > 0 else 0.0,
                     "share_of_step": region_ms / (elapsed / args.steps * 1e3),
-                    "flop_model": "12.0 TFLOP per image: towers 9.169 forward (frozen) + SVA side 0.940 x 3 (SURVEY.md §8d)"}
+                    "flop_model": "12.0 TFLOP per image: towers 9.169 forward (frozen) + SVA side 0.940 x 3 (SURVEY.md §8d) — the "
+                                  "REFERENCE algorithm's count, whatever this build executes",
+                    "absorbed_kv": bool(ABSORB_KV_ON),
+                    "executed_note": ("with the windowed tower's K / V projections absorbed into the query side (DESIGN.md §4 "
+                                      "'Absorbed K/V') the SVA side executes ~1.4 of its 2.8 TFLOP per image; the fraction above "
+                                      "stays on the reference's 12.0") if ABSORB_KV_ON else None}
             if prof_all:
                 fall, msall, nall = agg(prof_all, lambda x: x[3] == torch.bfloat16)
                 line["roofline"]["all_own_gemm"] = {
