@@ -57,7 +57,8 @@ struct AbsParams {
   const bf16_t* xhat; int64_t ldx;
   const uint8_t* mask_a;
   const bf16_t* U;
-  const float* cb;
+  const float* bk;   // b_k [1024] (fp32): cb[q,h] = b_k,h . q_h is formed here
+  const float* bv;   // b_v [1024] (fp32): the output carries m3[q,h] b_v,h
   bf16_t* out; int64_t ldo;
   bf16_t* xbar;
   float* m3;
@@ -65,7 +66,6 @@ struct AbsParams {
   // backward
   const bf16_t* dout; int64_t lddo;
   const bf16_t* dxbar;
-  const float* dm3;
   bf16_t* dq; int64_t lddq;
   bf16_t* dkv[kMaxD];
   bf16_t* dU;
@@ -216,7 +216,13 @@ __global__ void __launch_bounds__(64) sva_abs_fwd_kernel(const AbsParams p) {
         vraw[d] = load16(kr + kC);
       }
     }
-    const float cbh = p.cb[qi * kHeads + i];
+    float bkf[16], bvf[16];   // this lane's 16 channels of b_k, b_v (L2-resident)
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p.bk + ch + e), c = *reinterpret_cast<const f32x4_t*>(p.bv + ch + e);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bkf[e + j] = a[j]; bvf[e + j] = c[j]; }
+    }
     uint32_t valid = 0;   // bit r: token 4 qd + r exists and may be attended
     {
       const uint8_t* mka = p.mask_a ? p.mask_a + qi * na : nullptr;
@@ -226,10 +232,14 @@ __global__ void __launch_bounds__(64) sva_abs_fwd_kernel(const AbsParams p) {
         if (tk < na && !(mka && mka[tk] == 0)) valid |= 1u << r;
       }
     }
-    float sd[kMaxD];
+    float sd[kMaxD], cbh;
     {
       float qv[16];
       cvt16(qraw, qv);
+      float cacc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cacc += qv[e] * bkf[e];
+      cbh = qsum(cacc);   // b_k,h . q_h
 #pragma unroll
       for (int d = 0; d < kMaxD; ++d) {
         sd[d] = -INFINITY;
@@ -276,11 +286,11 @@ __global__ void __launch_bounds__(64) sva_abs_fwd_kernel(const AbsParams p) {
         p.m3[qi * kHeads + i] = m3v;
       }
     }
-    // ---- the direct towers' part of the output: sum_k p_k V_k
+    // ---- the direct towers' part of the output, sum_k p_k V_k, plus the absorbed tower's bias term m3 b_v
     {
       float o[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[e] = 0.f;
+      for (int e = 0; e < 16; ++e) o[e] = m3v * bvf[e];
 #pragma unroll
       for (int d = 0; d < kMaxD; ++d) {
         if (live[d]) {
@@ -343,10 +353,20 @@ __global__ void __launch_bounds__(64) sva_abs_bwd_kernel(const AbsParams p) {
     const float* prow = p.P + (qi * kHeads + i) * kPStride;
     const f32x4_t pa = *reinterpret_cast<const f32x4_t*>(prow + 4 + 4 * qd);
     const f32x4_t pdv = *reinterpret_cast<const f32x4_t*>(prow);
-    const float dm3h = p.dm3[qi * kHeads + i];
-    float qv[16], dov[16];
+    float qv[16], dov[16], bkf[16];
     cvt16(qraw, qv);
     cvt16(doraw, dov);
+    float dm3h;   // d m3[h] = b_v,h . do_h
+    {
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p.bk + ch + e), c = *reinterpret_cast<const f32x4_t*>(p.bv + ch + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bkf[e + j] = a[j]; acc += dov[e + j] * c[j]; }
+      }
+      dm3h = qsum(acc);
+    }
     // ---- dP of every key; D = sum_k P_k dP_k per head.  Direct towers: dP = do . V
     float pd[kMaxD], dsd[kMaxD];
     float D = 0.f;
@@ -386,11 +406,11 @@ __global__ void __launch_bounds__(64) sva_abs_bwd_kernel(const AbsParams p) {
       coef[(4 * qd + r) * 32 + i] = (bf16_t)pa[r];
       coef[(4 * qd + r) * 32 + 16 + i] = (bf16_t)ds[r];
     }
-    // ---- direct towers: dq += dS K, dK = dS q, dV = P do
+    // ---- dq = d(cb) b_k  +  over the direct towers dS K;  dK = dS q, dV = P do
     {
       float dq[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+      for (int e = 0; e < 16; ++e) dq[e] = dcb * bkf[e];
 #pragma unroll
       for (int d = 0; d < kMaxD; ++d) {
         if (d < p.ntowers) {
@@ -457,7 +477,7 @@ __global__ void __launch_bounds__(64) sva_abs_bwd_kernel(const AbsParams p) {
 }
 
 int fill(const cmb_sva_abs_desc* d, AbsParams& p, bool bwd) {
-  if (!d || !d->q || !d->xhat || !d->U || !d->cb || !d->out || !d->xbar || !d->m3 || !d->P) return CMB_ERR_BAD_ARG;
+  if (!d || !d->q || !d->xhat || !d->U || !d->bk || !d->bv || !d->out || !d->xbar || !d->m3 || !d->P) return CMB_ERR_BAD_ARG;
   if (d->B < 0 || d->qside <= 0 || d->heads != kHeads || d->hd != kHd) return CMB_ERR_SHAPE;
   if (d->ntowers < 0 || d->ntowers > kMaxD || d->ra <= 0 || d->ra * d->ra > kMaxKeys) return CMB_ERR_SHAPE;
   p.B = d->B; p.qside = d->qside; p.ntowers = d->ntowers; p.window_major = d->window_major;
@@ -473,15 +493,15 @@ int fill(const cmb_sva_abs_desc* d, AbsParams& p, bool bwd) {
   p.ra = d->ra;
   p.xhat = (const bf16_t*)d->xhat; p.ldx = d->ldx;
   p.mask_a = d->mask_a;
-  p.U = (const bf16_t*)d->U; p.cb = d->cb;
+  p.U = (const bf16_t*)d->U; p.bk = d->bk; p.bv = d->bv;
   p.out = (bf16_t*)d->out; p.ldo = d->ldo;
   p.xbar = (bf16_t*)d->xbar; p.m3 = d->m3; p.P = d->P;
   p.dout = (const bf16_t*)d->dout; p.lddo = d->lddo;
-  p.dxbar = (const bf16_t*)d->dxbar; p.dm3 = d->dm3;
+  p.dxbar = (const bf16_t*)d->dxbar;
   p.dq = (bf16_t*)d->dq; p.lddq = d->lddq;
   p.dU = (bf16_t*)d->dU; p.dcb = d->dcb;
   p.dxhat = (bf16_t*)d->dxhat; p.lddx = d->lddx;
-  if (bwd && (!d->dout || !d->dxbar || !d->dm3 || !d->dq || !d->dU || !d->dcb || !d->dxhat)) return CMB_ERR_BAD_ARG;
+  if (bwd && (!d->dout || !d->dxbar || !d->dq || !d->dU || !d->dcb || !d->dxhat)) return CMB_ERR_BAD_ARG;
   p.scale = 1.0f / sqrtf((float)d->hd);
   return CMB_OK;
 }

@@ -85,11 +85,11 @@ class SvaAbsDesc(C.Structure):
         ("ra", C.c_int32),
         ("xhat", C.c_void_p), ("ldx", C.c_int64),
         ("mask_a", C.c_void_p),
-        ("U", C.c_void_p), ("cb", C.c_void_p),
+        ("U", C.c_void_p), ("bk", C.c_void_p),
         ("out", C.c_void_p), ("ldo", C.c_int64),
         ("xbar", C.c_void_p), ("m3", C.c_void_p), ("P", C.c_void_p),
         ("dout", C.c_void_p), ("lddo", C.c_int64),
-        ("dxbar", C.c_void_p), ("dm3", C.c_void_p),
+        ("dxbar", C.c_void_p), ("bv", C.c_void_p),
         ("dq", C.c_void_p), ("lddq", C.c_int64),
         ("dkv", C.c_void_p * SVA_MAX_TOWERS),
         ("dU", C.c_void_p), ("dcb", C.c_void_p),

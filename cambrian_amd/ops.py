@@ -954,7 +954,7 @@ class HeadContractFn(torch.autograd.Function):
         return dxb, dw, None
 
 
-def _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, U, cb, B, qside, window_major):
+def _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, U, bk, bv, B, qside, window_major):
     d.B, d.qside, d.heads, d.hd = B, qside, 16, 64
     d.ntowers, d.window_major, d.ra = len(kvs), 1 if window_major else 0, ra
     d.q, d.ldq = q.data_ptr(), q.stride(0)
@@ -964,64 +964,69 @@ def _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, U, cb, B, qside, window_ma
         d.mask[i] = None if masks[i] is None else masks[i].data_ptr()
     d.xhat, d.ldx = xhat.data_ptr(), xhat.stride(0)
     d.mask_a = None if mask_a is None else mask_a.data_ptr()
-    d.U, d.cb = U.data_ptr(), cb.data_ptr()
+    d.U, d.bk, d.bv = U.data_ptr(), bk.data_ptr(), bv.data_ptr()
 
 
 class SvaAbsorbedFn(torch.autograd.Function):
     """cmb_sva_abs_fwd / _bwd: per query the joint softmax over the one-key towers' projected K|V rows and the windowed
-    tower's tokens (scored against U), returning (direct towers' part of the output [Bq, 1024], Xb [Bq, 16, 1024], m3 [Bq, 16])."""
+    tower's tokens (scored against U, plus b_k . q), returning (the direct towers' part of the output + m3 b_v [Bq, 1024],
+    Xb [Bq, 16, 1024])."""
 
     @staticmethod
-    def forward(ctx, q, U, cb, xhat, B: int, qside: int, ra: int, masks, mask_a, window_major: bool, *kvs):
-        L.require_gpu(q, U, cb, xhat, *kvs)
+    def forward(ctx, q, U, bk, bv, xhat, B: int, qside: int, ra: int, masks, mask_a, window_major: bool, *kvs):
+        L.require_gpu(q, U, bk, bv, xhat, *kvs)
         Bq = B * qside * qside
         if q.dtype != torch.bfloat16 or tuple(q.shape) != (Bq, 1024) or tuple(U.shape) != (Bq, 16, 1024):
             raise L.CambrianAmdError("absorbed SVA attention: bf16, 16 heads x 64, 1024-wide features")
         if xhat.shape[0] != B * (qside * ra) ** 2 or xhat.shape[1] != 1024 or xhat.stride(1) != 1:
             raise L.CambrianAmdError("absorbed SVA attention: xhat must be [B*(qside*ra)^2, 1024]")
         kvs = [kv if kv.stride(1) == 1 else kv.contiguous() for kv in kvs]
-        Uc, cbc = U.contiguous(), cb.to(torch.float32).contiguous()
+        Uc = U.contiguous()
+        bkc, bvc = bk.detach().to(torch.float32).contiguous(), bv.detach().to(torch.float32).contiguous()
         out = torch.empty((Bq, 1024), dtype=q.dtype, device=q.device)
         xbar = torch.empty((Bq, 16, 1024), dtype=q.dtype, device=q.device)
         m3 = torch.empty((Bq, 16), dtype=torch.float32, device=q.device)
         P = torch.empty((Bq, 16, 20), dtype=torch.float32, device=q.device)   # [0, 4) direct keys, [4, 20) window tokens
         d = L.SvaAbsDesc()
-        _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, Uc, cbc, B, qside, window_major)
+        _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, Uc, bkc, bvc, B, qside, window_major)
         d.out, d.ldo, d.xbar, d.m3, d.P = out.data_ptr(), out.stride(0), xbar.data_ptr(), m3.data_ptr(), P.data_ptr()
         L.check(L.load().cmb_sva_abs_fwd(C.byref(d), L.stream_ptr(q.device)), "cmb_sva_abs_fwd")
         ctx.cfg = (B, qside, ra, window_major)
         ctx.masks, ctx.mask_a = masks, mask_a
-        ctx.cb_dtype = cb.dtype
-        ctx.save_for_backward(q, Uc, cbc, xhat, P, *kvs)
+        ctx.b_dtypes = (bk.dtype, bv.dtype)
+        ctx.save_for_backward(q, Uc, bkc, bvc, xhat, P, m3, *kvs)
+        ctx.mark_non_differentiable(m3)
         return out, xbar, m3
 
     @staticmethod
-    def backward(ctx, dout, dxbar, dm3):
-        q, U, cb, xhat, P, *kvs = ctx.saved_tensors
+    def backward(ctx, dout, dxbar, _dm3):
+        q, U, bk, bv, xhat, P, m3, *kvs = ctx.saved_tensors
         B, qside, ra, window_major = ctx.cfg
         Bq = q.shape[0]
         dev = q.device
         dout = torch.zeros_like(q) if dout is None else _as_dtype_contig(dout, q.dtype)
         dxbar = torch.zeros_like(U) if dxbar is None else _as_dtype_contig(dxbar, q.dtype)
-        dm3 = torch.zeros((Bq, 16), dtype=torch.float32, device=dev) if dm3 is None else dm3.to(torch.float32).contiguous()
         dq = torch.empty_like(q)
         dkvs = [torch.empty_like(kv) for kv in kvs]
         dU = torch.empty_like(U)
         dcb = torch.empty((Bq, 16), dtype=torch.float32, device=dev)
         dxhat = torch.empty((xhat.shape[0], 1024), dtype=q.dtype, device=dev)
         d = L.SvaAbsDesc()
-        _fill_sva_abs(d, q, kvs, ctx.masks, xhat, ctx.mask_a, ra, U, cb, B, qside, window_major)
+        _fill_sva_abs(d, q, kvs, ctx.masks, xhat, ctx.mask_a, ra, U, bk, bv, B, qside, window_major)
         # (the forward outputs are not read by the backward kernel, but the descriptor's forward fields must be set)
         d.out, d.ldo, d.xbar, d.m3, d.P = dq.data_ptr(), dq.stride(0), dU.data_ptr(), dcb.data_ptr(), P.data_ptr()
-        d.dout, d.lddo, d.dxbar, d.dm3 = dout.data_ptr(), dout.stride(0), dxbar.data_ptr(), dm3.data_ptr()
+        d.dout, d.lddo, d.dxbar = dout.data_ptr(), dout.stride(0), dxbar.data_ptr()
         d.dq, d.lddq = dq.data_ptr(), dq.stride(0)
         for i, t in enumerate(dkvs):
             d.dkv[i] = t.data_ptr()
         d.dU, d.dcb, d.dxhat, d.lddx = dU.data_ptr(), dcb.data_ptr(), dxhat.data_ptr(), dxhat.stride(0)
         L.check(L.load().cmb_sva_abs_bwd(C.byref(d), L.stream_ptr(dev)), "cmb_sva_abs_bwd")
-        if ctx.cb_dtype != torch.float32:
-            dcb = dcb.to(ctx.cb_dtype)
-        return (dq, dU, dcb, dxhat, None, None, None, None, None, None, *dkvs)
+        dbk = dbv = None
+        if ctx.needs_input_grad[2]:   # d b_k[c] = sum_q d(cb)[q, h(c)] q[q, c]
+            dbk = (dcb[:, :, None] * q.view(Bq, 16, 64)).sum(0, dtype=torch.float32).reshape(1024).to(ctx.b_dtypes[0])
+        if ctx.needs_input_grad[3]:   # d b_v[c] = sum_q m3[q, h(c)] d out[q, c]
+            dbv = (m3[:, :, None] * dout.view(Bq, 16, 64)).sum(0, dtype=torch.float32).reshape(1024).to(ctx.b_dtypes[1])
+        return (dq, dU, dbk, dbv, dxhat, None, None, None, None, None, None, *dkvs)
 
 
 def sva_absorbed_attention(qh, kvs_direct, masks_direct, xhat, mask_a, ra: int, wk, bk, wv, bv, B: int, qside: int,
@@ -1031,13 +1036,9 @@ def sva_absorbed_attention(qh, kvs_direct, masks_direct, xhat, mask_a, ra: int, 
     ``xhat`` the windowed tower's normalised tokens; (wk, bk, wv, bv) its folded projection [1024, 1024] / [1024] (fp32,
     autograd-tracked).  Returns the attention output [Bq, 1024] (before o_proj), identical to ``sva_attention`` on the K|V
     rows ``xhat @ [wk; wv]^T + [bk; bv]``."""
-    Bq = qh.shape[0]
     U = HeadExpandFn.apply(qh, wk, 16)                                           # [Bq, 16, 1024]
-    cb = (qh.view(Bq, 16, 64).float() * bk.view(16, 64).float()).sum(-1)        # [Bq, 16]
-    out_d, xbar, m3 = SvaAbsorbedFn.apply(qh, U, cb, xhat, B, qside, ra, list(masks_direct), mask_a, window_major, *kvs_direct)
-    o3 = HeadContractFn.apply(xbar, wv, 16)                                      # [Bq, 1024]
-    ob = (m3[:, :, None] * bv.view(16, 64).float()).reshape(Bq, 1024).to(qh.dtype)
-    return out_d + o3 + ob
+    out_d, xbar, _ = SvaAbsorbedFn.apply(qh, U, bk, bv, xhat, B, qside, ra, list(masks_direct), mask_a, window_major, *kvs_direct)
+    return out_d + HeadContractFn.apply(xbar, wv, 16)                             # + W_v,h Xb
 
 
 # ================================================================================================

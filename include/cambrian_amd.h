@@ -249,15 +249,16 @@ int cmb_sva_attn_bwd(const cmb_sva_desc* d, void* stream);
  * (kv_i above) the caller supplies, for that tower,
  *   xhat : [B * (qside*ra)^2, 1024]  the LayerNorm-normalised tokens (affines folded into W_k, W_v, b_k, b_v)
  *   U    : [Bq, 16, 1024]            U[q,h,:] = W_k,h^T q_h           (cmb_gemm, batch = 16, K = 64)
- *   cb   : fp32 [Bq, 16]             cb[q,h] = b_k,h . q_h
+ *   bk, bv : fp32 [1024]             the folded K / V biases: the kernel forms cb[q,h] = b_k,h . q_h itself
  * and receives, besides the joint-softmax probabilities P (fp32 [Bq, 16, 20]: columns [0, 4) the direct towers' keys,
  * [4, 20) the absorbed tower's window tokens, zero where absent or masked; saved for the backward),
- *   out  : [Bq, 1024]   sum over the DIRECT towers' keys of p * V           (kv / mask / r as in cmb_sva_desc; r_i == 1)
- *   xbar : [Bq, 16, 1024]  Xb[q,h,:] = sum_t p[q,h,t] xhat_t     -> the absorbed tower's output is W_v,h Xb + m3 b_v,h
- *   m3   : fp32 [Bq, 16]   sum_t p[q,h,t] over the absorbed tower's tokens
+ *   out  : [Bq, 1024]   sum over the DIRECT towers' keys of p * V, plus m3[q,h] b_v,h   (kv / mask / r as in cmb_sva_desc; r_i == 1)
+ *   xbar : [Bq, 16, 1024]  Xb[q,h,:] = sum_t p[q,h,t] xhat_t     -> the layer's attention output is out + W_v,h Xb
+ *   m3   : fp32 [Bq, 16]   sum_t p[q,h,t] over the absorbed tower's tokens (kept by the caller: d b_v = sum_q m3 d out)
  * with score[q,h,t] = (xhat_t . U[q,h,:] + cb[q,h]) / sqrt(hd) for the absorbed tokens and q_h . K_h / sqrt(hd) for the
- * direct ones.  The backward takes d(out), d(xbar), d(m3) and writes dq (through the direct towers only), dkv of the direct
- * towers, dU, d(cb) and d(xhat) (every element exactly once).  Neither K|V nor dK|dV of the absorbed tower exist.
+ * direct ones.  The backward takes d(out), d(xbar) and writes dq (the direct towers' part and d(cb) b_k), dkv of the direct
+ * towers, dU, d(cb) (fp32 [Bq, 16]: d b_k = sum_q d(cb) q) and d(xhat) (every element exactly once).  Neither K|V nor
+ * dK|dV of the absorbed tower exist.
  * ---------------------------------------------------------------------------------------- */
 typedef struct cmb_sva_abs_desc {
   int32_t B, qside, heads, hd;
@@ -271,7 +272,7 @@ typedef struct cmb_sva_abs_desc {
   const void* xhat; int64_t ldx;
   const uint8_t* mask_a; /* uint8 [Bq, ra*ra] or NULL */
   const void* U;
-  const float* cb;
+  const float* bk;
   void* out;       int64_t ldo;
   void* xbar;
   float* m3;
@@ -279,7 +280,7 @@ typedef struct cmb_sva_abs_desc {
   /* backward only */
   const void* dout; int64_t lddo;
   const void* dxbar;
-  const float* dm3;
+  const float* bv;
   void* dq;         int64_t lddq;
   void* dkv[CMB_SVA_MAX_TOWERS];
   void* dU;

@@ -13,9 +13,9 @@ Bq, T = B * qside * qside, ra * ra
 g = torch.Generator().manual_seed(0)
 def rn(*s): return torch.randn(*s, generator=g).to(torch.bfloat16).to(dev)
 q = rn(Bq, 1024); kvs = [rn(Bq, 2048) for _ in range(3)]; xhat = rn(B * (qside * ra) ** 2, 1024)
-U = rn(Bq, 16, 1024) * 0.05; cb = torch.randn(Bq, 16, generator=g).to(dev)
+U = rn(Bq, 16, 1024) * 0.05; bk = torch.randn(1024, generator=g).to(dev); bv = torch.randn(1024, generator=g).to(dev)
 out = torch.empty_like(q); xbar = torch.empty_like(U); m3 = torch.empty(Bq, 16, device=dev); P = torch.empty(Bq, 16, 20, device=dev)
-dout = rn(Bq, 1024); dxbar = rn(Bq, 16, 1024); dm3 = torch.randn(Bq, 16, generator=g).to(dev)
+dout = rn(Bq, 1024); dxbar = rn(Bq, 16, 1024)
 dq = torch.empty_like(q); dkvs = [torch.empty_like(k) for k in kvs]; dU = torch.empty_like(U); dcb = torch.empty(Bq, 16, device=dev)
 dxhat = torch.empty_like(xhat)
 d = L.SvaAbsDesc()
@@ -23,9 +23,9 @@ d.B, d.qside, d.heads, d.hd, d.ntowers, d.window_major, d.ra = B, qside, 16, 64,
 d.q, d.ldq = q.data_ptr(), 1024
 for i, kv in enumerate(kvs):
     d.r[i] = 1; d.kv[i], d.ldkv[i] = kv.data_ptr(), 2048; d.mask[i] = None; d.dkv[i] = dkvs[i].data_ptr()
-d.xhat, d.ldx, d.mask_a, d.U, d.cb = xhat.data_ptr(), 1024, None, U.data_ptr(), cb.data_ptr()
+d.xhat, d.ldx, d.mask_a, d.U, d.bk, d.bv = xhat.data_ptr(), 1024, None, U.data_ptr(), bk.data_ptr(), bv.data_ptr()
 d.out, d.ldo, d.xbar, d.m3, d.P = out.data_ptr(), 1024, xbar.data_ptr(), m3.data_ptr(), P.data_ptr()
-d.dout, d.lddo, d.dxbar, d.dm3 = dout.data_ptr(), 1024, dxbar.data_ptr(), dm3.data_ptr()
+d.dout, d.lddo, d.dxbar = dout.data_ptr(), 1024, dxbar.data_ptr()
 d.dq, d.lddq, d.dU, d.dcb, d.dxhat, d.lddx = dq.data_ptr(), 1024, dU.data_ptr(), dcb.data_ptr(), dxhat.data_ptr(), 1024
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def timeit(fn, n=20):
