@@ -87,6 +87,43 @@ def cases():
         do = rn(B * 576, heads * hd)
         return lambda: ops.k_sva_attn_bwd(do, q, kvs, None, r_list, o, lse, B, qside, heads, hd)
     add("sva_bwd", "sva_bwd_kernel", "same", 2 * kv_bytes + 5 * q_bytes, mk_svab)
+    # ---- absorbed SVA attention core (round 3 default): window tower's tokens + U read, Xb written (forward); x, U, dXb read,
+    #      dU, dx written (backward); plus the one-key towers' K|V rows and q / out rows
+    def abs_desc():
+        import ctypes as C
+        Bq = B * 576
+        t = dict(q=rn(Bq, 1024), kvs=[rn(Bq, 2048) for _ in range(3)], xhat=rn(B * 9216, 1024), U=rn(Bq, 16, 1024) * 0.05,
+                 bk=rn(1024, dtype=f32), bv=rn(1024, dtype=f32), out=rn(Bq, 1024), xbar=rn(Bq, 16, 1024),
+                 m3=torch.empty(Bq, 16, device=dev), P=torch.empty(Bq, 16, 20, device=dev), dout=rn(Bq, 1024),
+                 dxbar=rn(Bq, 16, 1024), dq=rn(Bq, 1024), dU=rn(Bq, 16, 1024), dcb=torch.empty(Bq, 16, device=dev),
+                 dxhat=rn(B * 9216, 1024))
+        t["dkvs"] = [torch.empty_like(k) for k in t["kvs"]]
+        d = L.SvaAbsDesc()
+        d.B, d.qside, d.heads, d.hd, d.ntowers, d.window_major, d.ra = B, 24, 16, 64, 3, 0, 4
+        d.q, d.ldq = t["q"].data_ptr(), 1024
+        for i, kv in enumerate(t["kvs"]):
+            d.r[i] = 1
+            d.kv[i], d.ldkv[i], d.mask[i], d.dkv[i] = kv.data_ptr(), 2048, None, t["dkvs"][i].data_ptr()
+        d.xhat, d.ldx, d.mask_a, d.U, d.bk, d.bv = t["xhat"].data_ptr(), 1024, None, t["U"].data_ptr(), t["bk"].data_ptr(), t["bv"].data_ptr()
+        d.out, d.ldo, d.xbar, d.m3, d.P = t["out"].data_ptr(), 1024, t["xbar"].data_ptr(), t["m3"].data_ptr(), t["P"].data_ptr()
+        d.dout, d.lddo, d.dxbar = t["dout"].data_ptr(), 1024, t["dxbar"].data_ptr()
+        d.dq, d.lddq, d.dU, d.dcb, d.dxhat, d.lddx = t["dq"].data_ptr(), 1024, t["dU"].data_ptr(), t["dcb"].data_ptr(), t["dxhat"].data_ptr(), 1024
+        return d, t, C
+    big = B * 576 * 16 * 1024 * 2          # one [Bq, 16, 1024] bf16 tensor = the window tower's tokens = 302 MB at 16 images
+    small = B * 576 * 1024 * 2             # one [Bq, 1024] row set
+
+    def mk_absf():
+        d, t, C = abs_desc()
+        lib = L.load()
+        return lambda: (L.check(lib.cmb_sva_abs_fwd(C.byref(d), L.stream_ptr(dev)), "abs_fwd"), t)[0]
+    add("sva_abs_fwd", "sva_abs_fwd_kernel", f"{B}x576 q, 4x4 window, 3 one-key towers", 3 * big + 8 * small + B * 576 * 16 * 84, mk_absf)
+
+    def mk_absb():
+        d, t, C = abs_desc()
+        lib = L.load()
+        L.check(lib.cmb_sva_abs_fwd(C.byref(d), L.stream_ptr(dev)), "abs_fwd")
+        return lambda: (L.check(lib.cmb_sva_abs_bwd(C.byref(d), L.stream_ptr(dev)), "abs_bwd"), t)[0]
+    add("sva_abs_bwd", "sva_abs_bwd_kernel", "same", 5 * big + 15 * small + B * 576 * 16 * 84, mk_absb)
     # ---- RMSNorm family (decoder side, 16 x 2048 tokens x 4096)
     rows, D = B * 2048, 4096
 
