@@ -92,6 +92,9 @@ def parse():
     ap.add_argument("--no-gemm-pass", action="store_true",
                     help="skip the two extra profiled steps behind roofline.all_own_gemm")
     ap.add_argument("--gemm-report", type=str, default=None, help="write a per-shape table of the hot-path GEMM launches (JSON)")
+    ap.add_argument("--unfreeze-towers", action="store_true",
+                    help="--unfreeze_mm_vision_tower of the reference (SURVEY.md §8f N4): the four towers train too (fp32 master "
+                         "parameters, autograd operators); NOT the headline line — the release recipe keeps them frozen")
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (marks the line INVALID)")
     return ap.parse_args()
 
@@ -109,7 +112,7 @@ PRESETS = {
 }
 
 
-def build_model(dev, llm_layers=None, preset="8b"):
+def build_model(dev, llm_layers=None, preset="8b", unfreeze_towers=False):
     from cambrian_amd.model.language_model.cambrian_llama import (CambrianLlamaForCausalLM, apply_release_8b_vision_config,
                                                                 llama3_8b_config)
     geo = dict(PRESETS[preset]["llm"])
@@ -117,6 +120,7 @@ def build_model(dev, llm_layers=None, preset="8b"):
         geo["num_hidden_layers"] = llm_layers
     cfg = llama3_8b_config(**geo)
     apply_release_8b_vision_config(cfg)
+    cfg.unfreeze_mm_vision_tower = bool(unfreeze_towers)
     sva = PRESETS[preset]["sva"]
     depth = cfg.num_hidden_layers
     cfg.num_of_vision_sampler_layers = len([k for k in range(sva["n"]) if sva["start"] + k * sva["stride"] < depth])
@@ -135,7 +139,11 @@ def build_model(dev, llm_layers=None, preset="8b"):
     model = model.to(dev)
     for t in model.model.vision_tower_aux_list:
         t.load_model()
+    if unfreeze_towers:   # registered sub-modules, as initialize_vision_modules does for this mode (cambrian_arch.py:125-126)
+        model.model.vision_tower_aux_list = torch.nn.ModuleList(model.model.vision_tower_aux_list)
     train_keys = ("mm_projector", "pos_emb", "vision_sampler", "vision_sampler_layers", "vision_query", "image_newline")
+    if unfreeze_towers:
+        train_keys += ("vision_tower_aux_list",)
     for n, p in model.named_parameters():
         p.requires_grad_(any(k in n for k in train_keys))
     return model, cfg
@@ -404,7 +412,7 @@ def main():
     global ABSORB_KV_ON
     ABSORB_KV_ON = bool(_vs.ABSORB_KV)
 
-    model, cfg = build_model(dev, args.llm_layers, args.preset)
+    model, cfg = build_model(dev, args.llm_layers, args.preset, args.unfreeze_towers)
     cfg.fp8_projections = bool(args.fp8_projections)
     params = [p for p in model.parameters() if p.requires_grad]
     z3_units = None
@@ -604,6 +612,10 @@ def main():
             line["config"]["NOT_HEADLINE"] = (f"decoder preset {args.preset} ({PRESETS[args.preset]['name']}: BASELINE "
                                               f"configs[{3 if args.preset == '13b' else 4}] geometry); the headline is 8b")
             line["config"]["workload"] = line["config"]["workload"].replace("Llama-3-8B", PRESETS[args.preset]["name"])
+        if args.unfreeze_towers:
+            line["config"]["NOT_HEADLINE"] = ("--unfreeze_mm_vision_tower (SURVEY.md §8f N4): the towers train; the release recipe "
+                                              "and the headline line keep them frozen")
+            line["config"]["trainable_parameters"] = int(sum(p.numel() for p in params))
         if args.llm_layers is not None:
             line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"
         if prof:

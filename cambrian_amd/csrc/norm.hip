@@ -536,7 +536,7 @@ int ln_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t row
            int side, int grid_r, const float* gamma, const float* mean, const float* rstd, void* dx,
            int64_t lddx, float* dgamma, float* dbeta, float* dadd, hipStream_t s) {
   const int nch = nch_for(D);
-  if (nch > 4) return CMB_ERR_SHAPE;  // register budget: the backward supports D <= 2048
+  if (nch > 8) return CMB_ERR_SHAPE;  // register budget: the backward supports D <= 4096 (ConvNeXt-XXL stage 4: 3072)
   const int npos = grid_r * grid_r;
   const int64_t nwin = rows / npos;
   int64_t blocks = (nwin + 63) / 64;  // ~16 rows per wave: amortises the end-of-block atomics
@@ -547,8 +547,12 @@ int ln_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t row
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, TDx, 2, ACCUM>), dim3((unsigned)blocks, npos), dim3(256), smem, s,
                        (const T*)dy, lddy, (const T*)x, ldx, rows, (int)D, add, side, grid_r, gamma, mean, rstd,
                        (TDx*)dx, lddx, dgamma, dbeta, dadd);
-  else
+  else if (nch == 4)
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, TDx, 4, ACCUM>), dim3((unsigned)blocks, npos), dim3(256), smem, s,
+                       (const T*)dy, lddy, (const T*)x, ldx, rows, (int)D, add, side, grid_r, gamma, mean, rstd,
+                       (TDx*)dx, lddx, dgamma, dbeta, dadd);
+  else  // 2048 < D <= 4096: the per-lane partial sums spill into the AGPR half of the register file (one wave per SIMD)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, TDx, 8, ACCUM>), dim3((unsigned)blocks, npos), dim3(256), smem, s,
                        (const T*)dy, lddy, (const T*)x, ldx, rows, (int)D, add, side, grid_r, gamma, mean, rstd,
                        (TDx*)dx, lddx, dgamma, dbeta, dadd);
   CMB_CHECK_LAUNCH();

@@ -145,7 +145,8 @@ def _window_pos(rows, side, r):
 
 @pytest.mark.parametrize("name,dt", DTYPES)
 @pytest.mark.parametrize("D,affine,with_add", [(1024, True, False), (1024, False, True), (1152, True, False),
-                                               (1536, False, False), (384, True, False), (4096, True, False)])
+                                               (1536, False, False), (384, True, False), (4096, True, False),
+                                               (3072, True, False), (3072, False, True), (8192, True, False)])
 def test_layernorm_fwd_bwd(dev, name, dt, D, affine, with_add):
     ops, L = _ops()
     g = torch.Generator().manual_seed(D)
@@ -164,7 +165,7 @@ def test_layernorm_fwd_bwd(dev, name, dt, D, affine, with_add):
     y, mean, rstd = ops.k_layernorm_fwd(x.to(dev), gamma.to(dev) if affine else None, beta.to(dev) if affine else None,
                                         1e-5, add=add.to(dev) if with_add else None, side=side, grid_r=r if with_add else 1)
     assert rel_err(y, ref) < TOL[name]
-    if D > 2048:
+    if D > 4096:      # the backward holds a row in registers: D <= 4096 (ConvNeXt-XXL stage 4 trains at 3072)
         return
     dx, dg, db, da = ops.k_layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, gamma=gamma.to(dev) if affine else None,
                                          add=add.to(dev) if with_add else None, side=side, grid_r=r if with_add else 1)
