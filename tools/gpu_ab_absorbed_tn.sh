@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/c16; mkdir -p $O
+O=gpurun_out/ab; mkdir -p $O
 export TMPDIR=/tmp
 ( timeout 300 python -m pytest tests/test_gemm_tn_gpu.py tests/test_sva_absorbed_gpu.py -m gpu -q -x > $O/pytest_tn.log 2>&1; tail -15 $O/pytest_tn.log )
 X="--no-cpu-baseline --no-ab --no-masked-case --no-gemm-pass --no-calibration --batch 16 --steps 2 --warmup 1"
@@ -15,7 +15,7 @@ python - <<'P'
 import json
 for f in ("bench_tn","bench_notn","bench_noabs"):
     try:
-        d=json.load(open(f"gpurun_out/c16/{f}.json")); r=d.get("roofline",{})
+        d=json.load(open(f"gpurun_out/ab/{f}.json")); r=d.get("roofline",{})
         print(f, round(d["ms_per_step"],1), round(d["value"],3), "frac",round(r.get("frac",0),3), "region",round(r.get("region",{}).get("ms_per_step",0),1), round(r.get("region",{}).get("frac",0),3))
     except Exception as e: print(f, repr(e)[:300])
 P

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/c19; mkdir -p $O
+O=gpurun_out/pmc_abs; mkdir -p $O
 export TMPDIR=/tmp
 for k in sva_abs_fwd sva_abs_bwd; do
   ( timeout 120 python tools/bench_hbm_kernels.py --only $k --md $O/hbm_$k.md --json $O/hbm_$k.json > $O/hbm_$k.log 2>&1; tail -3 $O/hbm_$k.md )
