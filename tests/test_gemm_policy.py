@@ -62,3 +62,20 @@ def test_census_top_keeps_only_calibratable_problems(lib):
     top = c.top(8)
     assert top == [(65536, 6144, 1536, 1), (65536, 1536, 6144, 0), (147456, 2048, 1024, 0)]
     assert c.top(1) == [(65536, 6144, 1536, 1)]
+
+
+def test_tn_weight_gradient_policy_and_host_checks(lib):
+    """ops._tn_wgrad_wins: cmb_gemm_tn takes the query-side weight gradients (tools/bench_tn.py), the large products stay on
+    transposes + the NT kernels; cmb_gemm_tn validates its descriptor before any launch (no GPU here: the host checks are
+    what runs) and k_gemm_tn refuses CPU tensors like every other operator."""
+    import ctypes as C
+    import torch
+    from cambrian_amd import lib as L
+    from cambrian_amd import ops
+    assert ops._tn_wgrad_wins(9216, 1024, 1024) and ops._tn_wgrad_wins(9216, 2048, 1024) and ops._tn_wgrad_wins(13824, 1024, 1536)
+    assert not ops._tn_wgrad_wins(147456, 1024, 3072) and not ops._tn_wgrad_wins(9216, 4096, 4096)
+    assert not ops._tn_wgrad_wins(9216, 4096, 1024)
+    with pytest.raises(L.CambrianAmdError):
+        ops.k_gemm_tn(torch.zeros(64, 128, dtype=torch.bfloat16), torch.zeros(64, 128, dtype=torch.bfloat16))
+    d = L.GemmDesc()
+    assert lib.cmb_gemm_tn(C.byref(d), None) != 0                        # null operands: rejected before any launch
