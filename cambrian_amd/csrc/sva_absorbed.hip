@@ -26,9 +26,10 @@
 // lane quad) of S IS the B-operand layout of the 16x16x16 product, so P and dS never leave the registers between the
 // softmax and the token mix.  ds_read_b64_tr_b16 hands each lane 4 tokens (or heads) of ONE channel out of a row-major
 // image; its four 8-byte pieces per row are aimed at channels 8p + 4T + e so that the two tiles T = 0, 1 of a 32-channel
-// group leave a lane with 8 consecutive channels: 16-byte stores.  (The v_dot2c / v_fma forms of these products were
-// VALU-bound at one wave per SIMD: 372 us forward and 646 us backward per launch of 9216 queries against ~130 / ~220 us
-// of HBM traffic.)
+// group leave a lane with 8 consecutive channels: 16-byte stores.  Measured at 16 images (9216 queries): forward 209 us,
+// backward 373 us stand-alone = 5.1 / 4.8 TB/s over the 1069 / 1806 MB the kernels touch (PMC: every byte once;
+// profiles/r03_hbm_kernels_table.md).  (The v_dot2c / v_fma forms of these products were VALU-bound at one wave per SIMD:
+// 372 us forward and 646 us backward.)
 #include "common.h"
 
 namespace {
@@ -36,7 +37,7 @@ namespace {
 constexpr int kHeads = 16, kHd = 64, kC = 1024, kMaxKeys = 16;
 constexpr int kWinBytes = kMaxKeys * kC * 2;                       // one wave's token window in LDS: 32 KiB
 constexpr int kCoefBytes = kMaxKeys * 32 * 2;                      // backward: (P | dS)[t][32] bf16 per wave
-constexpr int kSmemFwd = kWinBytes;                  // one wave per workgroup: 5 (forward) / 4 (backward) per CU
+constexpr int kSmemFwd = kWinBytes;                  // one wave per workgroup, four workgroups per CU (LDS, and > 256 registers)
 constexpr int kSmemBwd = kWinBytes + kCoefBytes;
 constexpr int kMaxD = 4;      // directly projected towers (one key each) beside the absorbed one
 constexpr int kPStride = 20;  // P row of a (query, head): [0, 4) the direct towers' keys, [4, 20) the absorbed tokens
@@ -480,11 +481,16 @@ int fill(const cmb_sva_abs_desc* d, AbsParams& p, bool bwd) {
   if (!d || !d->q || !d->xhat || !d->U || !d->bk || !d->bv || !d->out || !d->xbar || !d->m3 || !d->P) return CMB_ERR_BAD_ARG;
   if (d->B < 0 || d->qside <= 0 || d->heads != kHeads || d->hd != kHd) return CMB_ERR_SHAPE;
   if (d->ntowers < 0 || d->ntowers > kMaxD || d->ra <= 0 || d->ra * d->ra > kMaxKeys) return CMB_ERR_SHAPE;
+  // 16-byte accesses everywhere: bases 16-byte aligned, row strides multiples of 8 elements
+  if (!cmb_aligned16(d->q) || !cmb_aligned16(d->xhat) || !cmb_aligned16(d->U) || !cmb_aligned16(d->out) || !cmb_aligned16(d->xbar) ||
+      !cmb_aligned16(d->P) || !cmb_aligned16(d->bk) || !cmb_aligned16(d->bv) || (d->ldq & 7) || (d->ldx & 7) || (d->ldo & 7))
+    return CMB_ERR_ALIGNMENT;
   p.B = d->B; p.qside = d->qside; p.ntowers = d->ntowers; p.window_major = d->window_major;
   p.q = (const bf16_t*)d->q; p.ldq = d->ldq;
   for (int i = 0; i < d->ntowers; ++i) {
     if (!d->kv[i]) return CMB_ERR_BAD_ARG;
     if (d->r[i] != 1) return CMB_ERR_SHAPE;   // directly projected towers: one key per query
+    if (!cmb_aligned16(d->kv[i]) || (d->ldkv[i] & 7) || (bwd && !cmb_aligned16(d->dkv[i]))) return CMB_ERR_ALIGNMENT;
     p.kv[i] = (const bf16_t*)d->kv[i]; p.ldkv[i] = d->ldkv[i];
     p.mask[i] = d->mask[i];
     p.dkv[i] = (bf16_t*)d->dkv[i];
@@ -501,6 +507,10 @@ int fill(const cmb_sva_abs_desc* d, AbsParams& p, bool bwd) {
   p.dq = (bf16_t*)d->dq; p.lddq = d->lddq;
   p.dU = (bf16_t*)d->dU; p.dcb = d->dcb;
   p.dxhat = (bf16_t*)d->dxhat; p.lddx = d->lddx;
+  if (bwd && d->dout && d->dq && d->dU && d->dxhat && d->dxbar &&
+      (!cmb_aligned16(d->dout) || !cmb_aligned16(d->dq) || !cmb_aligned16(d->dU) || !cmb_aligned16(d->dxhat) ||
+       !cmb_aligned16(d->dxbar) || (d->lddo & 7) || (d->lddq & 7) || (d->lddx & 7)))
+    return CMB_ERR_ALIGNMENT;
   if (bwd && (!d->dout || !d->dxbar || !d->dq || !d->dU || !d->dcb || !d->dxhat)) return CMB_ERR_BAD_ARG;
   p.scale = 1.0f / sqrtf((float)d->hd);
   return CMB_OK;
