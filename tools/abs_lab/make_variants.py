@@ -27,6 +27,7 @@ variants = {
     5: lambda s: sub(s, "  for (int j = 0; j < na; ++j) {\n    const bf16_t* xr = xb + token_row", "  for (int j = 0; j < (na > 99 ? na : 0); ++j) {\n    const bf16_t* xr = xb + token_row"),  # no window DMA
     6: lambda s: sub(s, "      for (int half = 0; half < 2; ++half) {", "      for (int half = 0; half < (na > 99 ? 2 : 0); ++half) {"),  # bwd: no dX pass
     7: lambda s: sub(s, "          if (i < na)\n            *reinterpret_cast<bf16x8_t*>(dxrow", "          if (i < na && dd[0][0] == 12345.678f)\n            *reinterpret_cast<bf16x8_t*>(dxrow"),  # dX computed, not stored
+    8: lambda s: sub(s, "__global__ void __launch_bounds__(64) sva_abs_fwd_kernel", "__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) sva_abs_fwd_kernel"),  # fwd <= 256 registers: 5 waves per CU
 }
 only = [int(a) for a in sys.argv[1:]] or sorted(variants)
 for n in only:

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from cambrian_amd import lib as L
 
 NAMES = {0: "baseline", 1: "token mixes not stored", 2: "no token mixes", 3: "score product: 1 of 32 MFMAs", 4: "U / dXb operand: 2 of 32 loads (U only)",
-         5: "no window DMA", 6: "bwd: no dX pass", 7: "bwd: dX not stored"}
+         5: "no window DMA", 6: "bwd: no dX pass", 7: "bwd: dX not stored", 8: "fwd limited to 256 registers (5 workgroups per CU)"}
 dev = torch.device("cuda:0")
 B, qside, ra = 16, 24, 4
 Bq, T = B * qside * qside, ra * ra
