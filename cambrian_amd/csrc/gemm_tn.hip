@@ -17,6 +17,7 @@
 // Epilogue (fp32 slabs for split-K, alpha / beta, fp32 or bf16 result), tile rasterisation and the accumulator layout are
 // gemm.hip's (gemm_common.h).  128 x 128 tile, 4 waves (2 x 2), each 64 x 64 as 2 x 2 v_mfma_f32_32x32x16_bf16 tiles.
 #include "gemm_common.h"
+#include "gemm_tn_layout.h"
 
 using namespace cmb_gemm_detail;
 
@@ -60,8 +61,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
   // ---- LDS-DMA sources.  An operand stage is 16 pieces of 1 KiB (4 rows each); wave w issues pieces w, w + 4, w + 8,
   // w + 12 of At and of Bt.  Lane l of a piece: row l >> 4, LDS slot l & 15 <- source slot (l & 15) ^ 4 (l >> 4).
   // Columns beyond M / N (whole 8-column slots: M, N are multiples of 8) re-read the tile's first slot; never stored.
-  const int kk = lane >> 4, sx = lane & 15;
-  const int sc = sx ^ (4 * kk);
+  const int sx = lane & 15;
+  const int sc = tn_dma_src_slot(lane);
   const int acol = (m0 + sc * 8 < p.M) ? (m0 + sc * 8) : m0;
   const int bcol = (n0 + sc * 8 < p.N) ? (n0 + sc * 8) : n0;
   const char* zsrc = g_zero_row + sx * 16;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
   int krow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    krow[i] = kbeg + 4 * (wave + 4 * i) + kk;
+    krow[i] = kbeg + tn_dma_row(wave + 4 * i, lane);
     a_src[i] = p.A + ((int64_t)krow[i] * lda + acol) * 2;
     b_src[i] = p.B + ((int64_t)krow[i] * ldb + bcol) * 2;
   }
@@ -79,8 +80,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bool live = krow[i] < kend;
-      glds16(live ? a_src[i] : zsrc, sa + (wave + 4 * i) * 1024);
-      glds16(live ? b_src[i] : zsrc, sa + OP_BYTES + (wave + 4 * i) * 1024);
+      glds16(live ? a_src[i] : zsrc, sa + tn_dma_lds_off(wave + 4 * i, 0));
+      glds16(live ? b_src[i] : zsrc, sa + OP_BYTES + tn_dma_lds_off(wave + 4 * i, 0));
       a_src[i] += (int64_t)BKR * lda * 2;
       b_src[i] += (int64_t)BKR * ldb * 2;
       krow[i] += BKR;
@@ -91,14 +92,11 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
   // [4 k][16 columns] block and receives column i of it (4 consecutive k).  The 32 columns of an MFMA fragment are the
   // blocks of 16-column subtiles 2 f + (q & 1); lanes 0-31 read 4-row piece 4 s + 2 r, lanes 32-63 piece 4 s + 2 r + 1
   // (k-step s, read r): byte offset inside the operand stage, without the (4 s + 2 r) KiB.
-  const int q = lane >> 4, bi = lane & 15;
-  const int brow = bi >> 2, bp = bi & 3;
   int a_off[2], b_off[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    const int msa = (wm * 64 + f * 32) / 16 + (q & 1), msb = (wn * 64 + f * 32) / 16 + (q & 1);
-    a_off[f] = (q >> 1) * 1024 + brow * 256 + (((2 * msa + (bp >> 1)) ^ (4 * brow)) << 4) + (bp & 1) * 8;
-    b_off[f] = OP_BYTES + (q >> 1) * 1024 + brow * 256 + (((2 * msb + (bp >> 1)) ^ (4 * brow)) << 4) + (bp & 1) * 8;
+    a_off[f] = tn_frag_off((wm * 64 + f * 32) / 16, lane);
+    b_off[f] = OP_BYTES + tn_frag_off((wn * 64 + f * 32) / 16, lane);
   }
 
   f32x16_t acc[2][2];
@@ -122,10 +120,10 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
         bf16x8_t a[2], b[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + a_off[f] + (4 * s) * 1024));
-          const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + a_off[f] + (4 * s + 2) * 1024));
-          const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + b_off[f] + (4 * s) * 1024));
-          const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + b_off[f] + (4 * s + 2) * 1024));
+          const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + a_off[f] + tn_frag_piece(s, 0) * 1024));
+          const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + a_off[f] + tn_frag_piece(s, 1) * 1024));
+          const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + b_off[f] + tn_frag_piece(s, 0) * 1024));
+          const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(base + b_off[f] + tn_frag_piece(s, 1) * 1024));
           const s16x8_t av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
           const s16x8_t bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
           a[f] = __builtin_bit_cast(bf16x8_t, av);

@@ -31,6 +31,7 @@
 // profiles/r03_hbm_kernels_table.md).  (The v_dot2c / v_fma forms of these products were VALU-bound at one wave per SIMD:
 // 372 us forward and 646 us backward.)
 #include "common.h"
+#include "sva_abs_layout.h"
 
 namespace {
 
@@ -102,17 +103,14 @@ __device__ __forceinline__ int64_t token_row(const AbsParams& p, int t, int qy, 
   return p.window_major ? ((int64_t)t * r * r + j) : ((int64_t)(qy * r + ry) * G + (qx * r + rx));
 }
 
-// LDS images.  A row is split into 1 KiB halves of 64 16-byte slots (8 channels each); slot c of row r is stored at slot
-// c ^ 4 (r & 15) of its half, so that the 16 rows a wave instruction touches at ONE channel offset spread over the banks
-// (rows are 1 or 2 KiB apart: without the rotation all of them start on bank 0 and a ds_read_b128 of the score product
-// runs 16-way conflicted).  LDS-DMA writes lane l's 16 bytes at + 16 l, so the rotation is applied to the lane's SOURCE.
+// LDS images and their slot rotation: sva_abs_layout.h (simulated on the host by tests/csrc/sva_abs_layout_sim.cpp).
 //
 // the query's window: token j's 1024 channels -> xs[j * 2048 ...] by two 1 KiB LDS-DMA instructions; asynchronous —
 // covered by the s_waitcnt vmcnt(0) in front of the first read
 __device__ __forceinline__ void stage_window(const AbsParams& p, const bf16_t* xb, char* xs, int na, int t, int qy, int qx,
                                              int lane) {
   for (int j = 0; j < na; ++j) {
-    const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx + ((lane ^ (4 * j)) & 63) * 8;
+    const bf16_t* xr = xb + token_row(p, t, qy, qx, p.ra, j) * p.ldx + abs_win_src_slot(lane, j) * 8;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xr,
                                      (__attribute__((address_space(3))) void*)(xs + j * 2048), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xr + 512),
@@ -151,10 +149,9 @@ __device__ __forceinline__ f32x4_t rows_dot(const char* xs, const bf16x8_t (&yv)
   f32x4_t acc[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const char* xr = xs + i * 2048 + qd * 16;
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
-    const bf16x8_t xa = *reinterpret_cast<const bf16x8_t*>(xr + (s >> 4) * 1024 + (((s & 15) ^ i) << 6));
+    const bf16x8_t xa = *reinterpret_cast<const bf16x8_t*>(xs + abs_rows_off(i, qd, s));
     acc[s & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, yv[s], acc[s & 3], 0, 0, 0);
   }
   return (acc[0] + acc[1]) + (acc[2] + acc[3]);
@@ -163,15 +160,12 @@ __device__ __forceinline__ f32x4_t rows_dot(const char* xs, const bf16x8_t (&yv)
 // out[h][c] = sum_t coef[t][h] X[t][c] for all 1024 channels (Xb from P, dU from dS): per 32-channel group two
 // transposing LDS reads + two 16x16x16 MFMAs; lane (i, qd) ends with head i, channels [32 cg + 8 qd, + 8): one 16-byte store
 __device__ __forceinline__ void token_mix(const char* xs, s16x4_t coef, bf16_t* orow, int i, int qd) {
-  // transposing read: this lane supplies row tk = 4 qd + i / 4 (token), piece i % 4 (channels 8 p + 4 T + e of the group)
-  const int tk = 4 * qd + (i >> 2);
-  const char* xr = xs + tk * 2048 + (i & 3) * 16;
+  // transposing read: this lane supplies row 4 qd + i / 4 (token), piece i % 4 (channels 8 p + 4 T + e of the group)
   bf16_t* op = orow + i * kC + qd * 8;
 #pragma unroll 4
   for (int cg = 0; cg < 32; ++cg) {
-    const char* a = xr + (cg >> 4) * 1024 + (((cg & 15) ^ tk) << 6);
-    const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)a);
-    const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(a + 8));
+    const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(xs + abs_mix_off(i, qd, cg, 0)));
+    const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(xs + abs_mix_off(i, qd, cg, 1)));
     const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
     const f32x4_t d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a0, coef, z, 0, 0, 0);
     const f32x4_t d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, coef, z, 0, 0, 0);
@@ -443,26 +437,22 @@ __global__ void __launch_bounds__(64) sva_abs_bwd_kernel(const AbsParams p) {
     //      them (U): no second trip to memory.  W^T by transposing reads, Coef^T from the scratch.
     {
       const bf16x8_t cf = *reinterpret_cast<const bf16x8_t*>(coef + i * 32 + qd * 8);   // Coef[k = 8 qd + j][t = i]
-      // transposing read: rows rw and rw + 4 of W (k = 8 qd + j), piece i % 4; write: rows i and 16 + i
-      const int rw = 8 * qd + (i >> 2);
-      const char* wr = xs + rw * 1024 + (i & 3) * 16;
-      char* ww = xs + i * 1024 + qd * 16;
+      // transposing read: rows 8 qd + i / 4 and + 4 of W (k = 8 qd + j), piece i % 4; write: rows i (dXb) and 16 + i (U)
       bf16_t* dxrow = p.dxhat + (xbase + token_row(p, t, qy, qx, p.ra, i < na ? i : 0)) * p.lddx + qd * 8;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-          *reinterpret_cast<bf16x8_t*>(ww + ((s ^ i) << 6)) = dxv[half * 16 + s];
-          *reinterpret_cast<bf16x8_t*>(ww + 16 * 1024 + ((s ^ i) << 6)) = uv[half * 16 + s];
+          *reinterpret_cast<bf16x8_t*>(xs + abs_w_write_off(i, qd, s)) = dxv[half * 16 + s];
+          *reinterpret_cast<bf16x8_t*>(xs + abs_w_write_off(16 + i, qd, s)) = uv[half * 16 + s];
         }
 #pragma unroll 2
         for (int cg = 0; cg < 16; ++cg) {
           f32x4_t dd[2];
 #pragma unroll
           for (int T = 0; T < 2; ++T) {
-            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(wr + ((cg ^ (rw & 15)) << 6) + T * 8));
-            const s16x4_t hi =
-                __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(wr + 4 * 1024 + ((cg ^ ((rw + 4) & 15)) << 6) + T * 8));
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(xs + abs_w_read_off(i, qd, 0, cg, T)));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(xs + abs_w_read_off(i, qd, 1, cg, T)));
             const s16x8_t a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             dd[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), cf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0,
                                                             0, 0);
