@@ -554,10 +554,19 @@ TN_WGRAD = os.environ.get("CAMBRIAN_AMD_TN_WGRAD", "1") != "0"
 
 def _tn_wgrad_wins(rows: int, n_out: int, k_in: int) -> bool:
     """Where dW = g^T x on cmb_gemm_tn beats transposed copies + the 256-tile NT kernels (tools/bench_tn.py,
-    profiles/r03c_wgrad_tn_vs_nt.md): weight matrices up to 2048 x 1024 at the query-side row counts.  The 128 x 128 TN tile
-    runs 350-900 TFLOP/s; the large products (the ConvNeXt-side projector at 147456 rows, the 4096-wide mm_projector)
-    stay on the 4-wave NT kernel at 1.0-1.25 PFLOP/s even with their transposes paid."""
-    return n_out * k_in <= 2048 * 1024 and rows <= 32768
+    profiles/r03c_wgrad_tn_vs_nt.md): every weight of up to 256 output tiles (4096 x 1024), with one exception — the
+    ConvNeXt-side projector's 1024 x 3072 at 147456 rows (192 tiles: two row slices of 74 k rows each run 1.5 rounds; 1556
+    vs 1323 us).  The 4096 x 4096 mm_projector weight (1024 tiles, no split) stays on the 4-wave NT kernel (341 vs 303 us)."""
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    return tiles <= 256 and not (rows > 65536 and tiles > 128)
+
+
+def _tn_splits(m_cols: int, n_cols: int, rows: int, batch: int = 1) -> int:
+    """Split-K factor of a cmb_gemm_tn weight gradient: as many row slices as fill ONE round of the kernel's two workgroups
+    per CU (512 on the 256-CU part).  Measured (13824 x 1024 x 1024: 2 / 4 / 8 / 12 / 16 slices = 112 / 67 / 52 / 65 / 67 us;
+    2048 x 1024: best at 4; 1024 x 1152: best at 6): one full round beats 1.5 rounds with smaller slabs."""
+    tiles = batch * ((m_cols + 127) // 128) * ((n_cols + 127) // 128)
+    return max(1, min(512 // max(tiles, 1), rows // 128, 64))
 
 
 def _wgrad_splits(n_out: int, k_in: int, m_pad: int, kstep: int) -> int:
@@ -642,7 +651,7 @@ class LinearFn(torch.autograd.Function):
         if need_w:
             if dt == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and x.stride(1) == 1 and TN_WGRAD and _tn_wgrad_wins(M, N, K):
                 # dW = g^T x with g and x as they lie (cmb_gemm_tn: transposing LDS reads, rows beyond M contribute zero)
-                dw = k_gemm_tn(g, x, split_k=_wgrad_splits(N, K, pad_to(M, 64), 64))
+                dw = k_gemm_tn(g, x, split_k=_tn_splits(N, K, M))
             else:  # fp32 parity path / odd widths: transposed copies for the NT kernel
                 m_pad = pad_to(M, ks)
                 g_t = k_transpose(g, m_pad)  # [N, M_pad]
@@ -906,7 +915,7 @@ class HeadExpandFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty((C, Cin), dtype=torch.float32, device=x.device)
             k_gemm_tn(x, dU.view(Bq, heads * Cin), out=dw, M=hd, N=Cin, batch=heads, a_bs=hd, b_bs=Cin, c_bs=hd * Cin, ldc=Cin,
-                      split_k=_wgrad_splits(C, Cin, pad_to(Bq, 64), 64))
+                      split_k=_tn_splits(hd, Cin, Bq, heads))
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         return dx, dw, None
@@ -948,7 +957,7 @@ class HeadContractFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty((C, Cin), dtype=torch.float32, device=xb.device)
             k_gemm_tn(dy, xb.view(Bq, heads * Cin), out=dw, M=hd, N=Cin, batch=heads, a_bs=hd, b_bs=Cin, c_bs=hd * Cin, ldc=Cin,
-                      split_k=_wgrad_splits(C, Cin, pad_to(Bq, 64), 64))
+                      split_k=_tn_splits(hd, Cin, Bq, heads))
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         return dxb, dw, None

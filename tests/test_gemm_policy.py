@@ -73,8 +73,11 @@ def test_tn_weight_gradient_policy_and_host_checks(lib):
     from cambrian_amd import lib as L
     from cambrian_amd import ops
     assert ops._tn_wgrad_wins(9216, 1024, 1024) and ops._tn_wgrad_wins(9216, 2048, 1024) and ops._tn_wgrad_wins(13824, 1024, 1536)
+    assert ops._tn_wgrad_wins(9216, 4096, 1024) and ops._tn_wgrad_wins(9216, 1024, 4096) and ops._tn_wgrad_wins(147456, 1024, 1024)
     assert not ops._tn_wgrad_wins(147456, 1024, 3072) and not ops._tn_wgrad_wins(9216, 4096, 4096)
-    assert not ops._tn_wgrad_wins(9216, 4096, 1024)
+    # split-K of the TN kernel: one round of its two workgroups per CU (512), never more slices than 128-row pieces
+    assert ops._tn_splits(1024, 1024, 9216) == 8 and ops._tn_splits(2048, 1024, 13824) == 4 and ops._tn_splits(4096, 4096, 9216) == 1
+    assert ops._tn_splits(64, 1024, 9216, 16) == 4 and ops._tn_splits(1024, 1024, 100) == 1
     with pytest.raises(L.CambrianAmdError):
         ops.k_gemm_tn(torch.zeros(64, 128, dtype=torch.bfloat16), torch.zeros(64, 128, dtype=torch.bfloat16))
     d = L.GemmDesc()

@@ -22,12 +22,13 @@ def timeit(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-print("| rows | n_out | k_in | splits | tn us | tn TF/s | transposes+nt us | of which gemm us | nt TF/s |\n|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+print("| rows | n_out | k_in | splits nt/tn | tn us | tn TF/s | transposes+nt us | of which gemm us | nt TF/s |\n|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
 for rows, n, k in SHAPES:
     g = torch.randn(rows, n, device=dev).to(torch.bfloat16)
     x = torch.randn(rows, k, device=dev).to(torch.bfloat16)
-    sp = ops._wgrad_splits(n, k, pad_to(rows, 64), 64)
-    t_tn = timeit(lambda: ops.k_gemm_tn(g, x, split_k=sp))
+    sp = ops._wgrad_splits(n, k, pad_to(rows, 64), 64)       # the NT path's split
+    spt = ops._tn_splits(n, k, rows)                            # the TN path's split
+    t_tn = timeit(lambda: ops.k_gemm_tn(g, x, split_k=spt))
     mp = pad_to(rows, 64)
     def old():
         gt, xt = ops.k_transpose(g, mp), ops.k_transpose(x, mp)
@@ -36,5 +37,5 @@ for rows, n, k in SHAPES:
     gt, xt = ops.k_transpose(g, mp), ops.k_transpose(x, mp)
     t_g = timeit(lambda: ops.k_gemm(gt, xt, out_dtype=torch.float32, split_k=sp))
     fl = 2.0 * rows * n * k
-    print(f"| {rows} | {n} | {k} | {sp} | {t_tn:.1f} | {fl / t_tn / 1e6:.0f} | {t_old:.1f} | {t_g:.1f} | {fl / t_g / 1e6:.0f} |", flush=True)
+    print(f"| {rows} | {n} | {k} | {sp}/{spt} | {t_tn:.1f} | {fl / t_tn / 1e6:.0f} | {t_old:.1f} | {t_g:.1f} | {fl / t_g / 1e6:.0f} |", flush=True)
     del g, x, gt, xt
