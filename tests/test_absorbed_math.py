@@ -41,3 +41,30 @@ def test_absorbed_equals_direct(T, nsmall):
         assert torch.allclose(a, b.to(a.dtype), atol=1e-8, rtol=1e-6)
     # masked keys of the windowed tower get exactly zero gradient in both forms
     assert torch.count_nonzero(grads[1][1][~mask_a]) == 0
+
+
+def test_absorbed_tower_selection(monkeypatch):
+    """VisionCrossAttentionLayer._absorbed_tower: which configuration takes the absorbed path — bf16, 1024-wide features,
+    exactly one windowed tower (up to 4 x 4) beside at most four one-key towers, fp8 projections off, switch on."""
+    import cambrian_amd.model.vision_sampler as VS
+    from cambrian_amd import ops
+
+    def layer(sizes):
+        return VS.VisionCrossAttentionLayer(1024, 1024, [1024] * len(sizes), sizes, 1024, 0)
+
+    q16, q32 = torch.zeros(4, 1024, dtype=torch.bfloat16), torch.zeros(4, 1024)
+    feats = lambda sizes, d=1024: [torch.zeros(4 * s * s, d, dtype=torch.bfloat16) for s in sizes]
+    rel = [1, 1, 1, 4]
+    monkeypatch.setattr(VS, "ABSORB_KV", True)
+    assert layer(rel)._absorbed_tower(q16, feats(rel)) == 3                       # the release tower set
+    assert layer([4, 1])._absorbed_tower(q16, feats([4, 1])) == 0
+    assert layer(rel)._absorbed_tower(q32, feats(rel)) == -1                      # fp32 parity path: per-token K|V
+    assert layer([1, 1, 2, 4])._absorbed_tower(q16, feats([1, 1, 2, 4])) == -1    # two windowed towers
+    assert layer([1, 1, 1, 1])._absorbed_tower(q16, feats([1, 1, 1, 1])) == -1    # none
+    assert layer([1, 8])._absorbed_tower(q16, feats([1, 8])) == -1                # window larger than 4 x 4
+    assert layer([1] * 5 + [4])._absorbed_tower(q16, feats([1] * 5 + [4])) == -1  # more than four one-key towers
+    monkeypatch.setattr(ops, "_FP8_LINEAR", True, raising=False)
+    assert layer(rel)._absorbed_tower(q16, feats(rel)) == -1                      # config.fp8_projections
+    monkeypatch.setattr(ops, "_FP8_LINEAR", False, raising=False)
+    monkeypatch.setattr(VS, "ABSORB_KV", False)
+    assert layer(rel)._absorbed_tower(q16, feats(rel)) == -1                      # CAMBRIAN_AMD_ABSORB_KV=0
