@@ -280,7 +280,7 @@ typedef struct cmb_sva_abs_desc {
   /* backward only */
   const void* dout; int64_t lddo;
   const void* dxbar;
-  const float* bv;
+  const float* bv;       /* (forward AND backward: see bk, bv above) */
   void* dq;         int64_t lddq;
   void* dkv[CMB_SVA_MAX_TOWERS];
   void* dU;
