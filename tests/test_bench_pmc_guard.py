@@ -40,3 +40,30 @@ def test_committed_summary_matches_the_committed_sources():
     if rec is None:   # not a failure (bench.py then reports traffic: null), but say so
         pytest.skip("profiles/r02_pmc_gemm_p5.json is stale: re-run tools/pmc_traffic.sh + tools/pmc_summarise.py on a GPU box")
     assert rec["write_bytes"] == 2 * rec["shape"][0] * rec["shape"][1] or abs(rec["write_bytes"] / (2 * rec["shape"][0] * rec["shape"][1]) - 1) < 0.01
+
+
+def test_committed_driver_lines_keep_the_bench_contract():
+    """The lines `python3 bench.py --gpus 1 --steps 20 --warmup 5` printed on the GPU (committed under profiles/): every key of
+    the bench contract, `roofline` and `cpu_baseline` objects complete, fractions consistent with their own numerators."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03c_bench_driver_cmd_run*.json")))
+    assert len(files) >= 3
+    for f in files:
+        with open(f) as fh:
+            d = json.load(fh)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (f, k)
+        assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+        assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["scaling"] == "weak" and "workload" in d["config"]
+        B = d["config"]["global_batch"]
+        assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6          # images/s = batch / step time
+        r = d["roofline"]
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None and r["traffic"] > 1e9
+        reg = r["region"]
+        assert abs(reg["frac"] - reg["algorithmic_tflop_per_step"] / (reg["ms_per_step"] * 1e-3) / 2500.0) < 1e-9
+        assert abs(reg["algorithmic_tflop_per_step"] - 12.0 * B) / (12.0 * B) < 0.01         # the reference's 12.0 TFLOP per image
+        assert reg["ms_per_step"] < d["ms_per_step"] and reg.get("absorbed_kv") is True
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
