@@ -35,8 +35,9 @@ def direct(qh, kv_small, masks_small, xhat, mask_a, wk, bk, wv, bv, heads=16):
     return (p @ v).transpose(1, 2).reshape(Bq, C)
 
 
-def absorbed_parts(qh, kv_small, masks_small, xhat, mask_a, U, cb, heads=16):
-    """The part cmb_sva_abs_fwd computes: (out_direct [Bq, C], xbar [Bq, H, Cin], m3 [Bq, H], P [Bq, H, nkeys])."""
+def absorbed_parts(qh, kv_small, masks_small, xhat, mask_a, U, cb, heads=16, mix_dtype=None):
+    """The part cmb_sva_abs_fwd computes: (out_direct [Bq, C], xbar [Bq, H, Cin], m3 [Bq, H], P [Bq, H, nkeys]).
+    ``mix_dtype`` = torch.bfloat16 rounds the window tokens' probabilities before the token mix, as the MFMA operand does."""
     Bq, C = qh.shape
     hd = C // heads
     scale = 1.0 / math.sqrt(hd)
@@ -54,11 +55,12 @@ def absorbed_parts(qh, kv_small, masks_small, xhat, mask_a, U, cb, heads=16):
     for i, kv in enumerate(kv_small):
         out = out + P[:, :, i, None] * _acc(kv[:, C:].view(Bq, heads, hd))
     pa = P[:, :, nd:]
-    xbar = torch.einsum("qht,qtc->qhc", pa, _acc(xhat))
+    pmix = pa if mix_dtype is None else pa.to(mix_dtype).to(pa.dtype)
+    xbar = torch.einsum("qht,qtc->qhc", pmix, _acc(xhat))
     return out.reshape(Bq, C), xbar, pa.sum(-1), P
 
 
-def absorbed(qh, kv_small, masks_small, xhat, mask_a, wk, bk, wv, bv, heads=16):
+def absorbed(qh, kv_small, masks_small, xhat, mask_a, wk, bk, wv, bv, heads=16, mix_dtype=None):
     """The whole absorbed form, composed as cambrian_amd/model/vision_sampler.py composes it."""
     Bq, C = qh.shape
     hd = C // heads
@@ -66,6 +68,6 @@ def absorbed(qh, kv_small, masks_small, xhat, mask_a, wk, bk, wv, bv, heads=16):
     q = _acc(qh.view(Bq, heads, hd))
     U = torch.einsum("qhj,hjc->qhc", q, _acc(wk.view(heads, hd, Cin)))
     cb = (q * _acc(bk.view(heads, hd))).sum(-1)
-    out, xbar, m3, _ = absorbed_parts(qh, kv_small, masks_small, xhat, mask_a, U, cb, heads)
+    out, xbar, m3, _ = absorbed_parts(qh, kv_small, masks_small, xhat, mask_a, U, cb, heads, mix_dtype)
     o3 = torch.einsum("qhc,hjc->qhj", xbar, _acc(wv.view(heads, hd, Cin))) + m3[:, :, None] * _acc(bv.view(heads, hd))
     return out + o3.reshape(Bq, C)

@@ -68,3 +68,20 @@ def test_absorbed_tower_selection(monkeypatch):
     monkeypatch.setattr(ops, "_FP8_LINEAR", False, raising=False)
     monkeypatch.setattr(VS, "ABSORB_KV", False)
     assert layer(rel)._absorbed_tower(q16, feats(rel)) == -1                      # CAMBRIAN_AMD_ABSORB_KV=0
+
+
+def test_bf16_probabilities_in_the_token_mix_cost_less_than_a_bf16_ulp_of_the_output():
+    """The MFMA token mix takes the probabilities as bf16 operands (as every MFMA attention kernel does).  On release-sized
+    rows (1024 channels, 16 tokens, unit-variance activations) the output moves by < 3e-3 of its range — below the bf16
+    rounding of the output itself (2^-8), which is why tests/test_sva_absorbed_gpu.py can keep the per-token path's bounds."""
+    g = torch.Generator().manual_seed(2)
+    Bq, H, hd, Cin, T = 64, 16, 64, 1024, 16
+    C = H * hd
+    rn = lambda *s: torch.randn(*s, generator=g)
+    qh, xhat = rn(Bq, C), rn(Bq, T, Cin)
+    kv_small = [rn(Bq, 2 * C) for _ in range(3)]
+    wk, wv, bk, bv = 0.03 * rn(C, Cin), 0.03 * rn(C, Cin), 0.5 * rn(C), 0.5 * rn(C)
+    exact = absorbed(qh, kv_small, [None] * 3, xhat, None, wk, bk, wv, bv)
+    rounded = absorbed(qh, kv_small, [None] * 3, xhat, None, wk, bk, wv, bv, mix_dtype=torch.bfloat16)
+    err = ((exact - rounded).abs().max() / exact.abs().max()).item()
+    assert 0 < err < 3e-3, err
