@@ -85,3 +85,41 @@ def test_bf16_probabilities_in_the_token_mix_cost_less_than_a_bf16_ulp_of_the_ou
     rounded = absorbed(qh, kv_small, [None] * 3, xhat, None, wk, bk, wv, bv, mix_dtype=torch.bfloat16)
     err = ((exact - rounded).abs().max() / exact.abs().max()).item()
     assert 0 < err < 3e-3, err
+
+
+def test_absorbed_form_reproduces_the_oracle_attention():
+    """One hop from the reference: oracle.sva.multi_kv_cross_attention restates vision_sampler.py:177-234 and is pinned by
+    tests/test_oracle_golden.py to fixtures the REAL reference produced.  The absorbed form — LayerNorm affines folded into
+    the projections (ops.fold_kv), the 4 x 4-window tower's K / V projections applied on the query side — gives its output
+    on the same parameters and inputs (fp32, masks on both kinds of key)."""
+    from oracle import sva as O
+    g = torch.Generator().manual_seed(11)
+    hidden, sizes, Bq = 1024, [1, 1, 4], 6
+    p = O.init_sampler_params(hidden, hidden, [hidden] * 3, sizes, hidden, 1, g)
+    pre = "layers.0.cross_attn."
+    for k in list(p):                                   # non-trivial LayerNorm affines
+        if ".0.weight" in k or ".0.bias" in k:
+            p[k] = p[k] + 0.3 * torch.randn(p[k].shape, generator=g)
+    x = torch.randn(Bq, 1, hidden, generator=g)
+    kvs = [torch.randn(Bq, s * s, hidden, generator=g) for s in sizes]
+    masks = [torch.rand(Bq, 1, 1, s * s, generator=g) > 0.3 for s in sizes]
+    masks[0][:] = True
+    masks[2][..., 0] = True
+    want = O.multi_kv_cross_attention(p, pre, x, kvs, masks)
+
+    def norm(t):
+        return (t - t.mean(-1, keepdim=True)) * torch.rsqrt(t.var(-1, unbiased=False, keepdim=True) + 1e-5)
+
+    def folded(i, kind):
+        w, gam, bet = p[f"{pre}{kind}_proj_{i}.1.weight"], p[f"{pre}{kind}_proj_{i}.0.weight"], p[f"{pre}{kind}_proj_{i}.0.bias"]
+        return w * gam[None, :], w @ bet
+    qh = (O.layer_norm(x, p[pre + "q_proj.0.weight"], p[pre + "q_proj.0.bias"]) @ p[pre + "q_proj.1.weight"].T).view(Bq, hidden)
+    kv_small = []
+    for i in (0, 1):
+        (wk, bk), (wv, bv) = folded(i, "k"), folded(i, "v")
+        xh = norm(kvs[i]).view(Bq, hidden)
+        kv_small.append(torch.cat([xh @ wk.T + bk, xh @ wv.T + bv], -1))
+    (wk, bk), (wv, bv) = folded(2, "k"), folded(2, "v")
+    got = absorbed(qh, kv_small, [m.view(Bq) for m in masks[:2]], norm(kvs[2]), masks[2].view(Bq, 16), wk, bk, wv, bv)
+    got = got @ p[pre + "o_proj.weight"].T
+    assert torch.allclose(got, want.view(Bq, hidden), atol=2e-5, rtol=1e-4), (got - want.view(Bq, hidden)).abs().max()
