@@ -437,8 +437,14 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
       if (p.P) tail.P += row_off(p.p_map, (uint32_t)m1) * 2;
       const int kern = choose_bf16_kernel(head, 1, 256, &sched);   // (256: the 256-tile branch of the cost model, no policy)
       g_last_kernel = kern;
-      rc = kern == 2590 ? launch_gemm_p5_bf16(head, 1, s) : launch_gemm256_bf16(head, 1, sched, s);
-      if (rc == CMB_OK) rc = launch_gemm<T, 128, 128, 2, 2>(tail, 1, s);
+      if (kern == 128) {
+        // the cost model refused the 256-tile kernels for the head (tile_span_fits_u32: their 32-bit per-lane offsets
+        // cannot span this row stride): no split, the whole problem on the 128-tile kernel as before the tail split
+        rc = launch_gemm<T, 128, 128, 2, 2>(p, 1, s);
+      } else {
+        rc = kern == 2590 ? launch_gemm_p5_bf16(head, 1, s) : launch_gemm256_bf16(head, 1, sched, s);
+        if (rc == CMB_OK) rc = launch_gemm<T, 128, 128, 2, 2>(tail, 1, s);
+      }
     } else {
       const int kern = choose_bf16_kernel(p, splits, d->tile_hint, &sched);
       g_last_kernel = kern;

@@ -649,7 +649,9 @@ class LinearFn(torch.autograd.Function):
             else:
                 dx = k_gemm(g, w_t)
         if need_w:
-            if dt == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and x.stride(1) == 1 and TN_WGRAD and _tn_wgrad_wins(M, N, K):
+            if (dt == torch.bfloat16 and M > 0 and N % 8 == 0 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0
+                    and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and g.stride(1) == 1 and g.stride(0) % 8 == 0
+                    and TN_WGRAD and _tn_wgrad_wins(M, N, K)):  # everything cmb_gemm_tn checks (gemm_tn_dispatch)
                 # dW = g^T x with g and x as they lie (cmb_gemm_tn: transposing LDS reads, rows beyond M contribute zero)
                 dw = k_gemm_tn(g, x, split_k=_tn_splits(N, K, M))
             else:  # fp32 parity path / odd widths: transposed copies for the NT kernel
@@ -989,7 +991,9 @@ class SvaAbsorbedFn(torch.autograd.Function):
             raise L.CambrianAmdError("absorbed SVA attention: bf16, 16 heads x 64, 1024-wide features")
         if xhat.shape[0] != B * (qside * ra) ** 2 or xhat.shape[1] != 1024 or xhat.stride(1) != 1:
             raise L.CambrianAmdError("absorbed SVA attention: xhat must be [B*(qside*ra)^2, 1024]")
-        kvs = [kv if kv.stride(1) == 1 else kv.contiguous() for kv in kvs]
+        # dense rows: the backward kernel writes dK|dV with the K|V row stride (cmb_sva_abs_desc has no separate lddkv) into
+        # torch.empty_like(kv), which is contiguous whatever kv's strides were
+        kvs = [kv.contiguous() for kv in kvs]
         Uc = U.contiguous()
         bkc, bvc = bk.detach().to(torch.float32).contiguous(), bv.detach().to(torch.float32).contiguous()
         out = torch.empty((Bq, 1024), dtype=q.dtype, device=q.device)
@@ -1294,9 +1298,11 @@ class GatherQueryRowsFn(torch.autograd.Function):
     ``link`` (a dict shared with the ScatterQueryRowsFn of the same hook, or None): the hook reads these rows of
     ``hidden`` and then overwrites exactly them, so d(hidden) = [text / newline rows: the scatter's incoming gradient;
     query rows: this gather's].  Returned as two dense tensors autograd would zero-fill one, clone the other and add
-    them (4 extra passes over [B,S,H] per hook).  With a link the scatter's backward — autograd runs it first — leaves
-    its result in ``link["dh"]`` and this backward writes its rows into that buffer and returns None (a consumer that
-    returns no gradient adds nothing; the decoder layer's backward runs only after both nodes)."""
+    them (4 extra passes over [B,S,H] per hook).  With a link the scatter's backward — which always runs first: this
+    node's incoming gradient is computed from the scatter's d(rows) — HANDS its dense result over in ``link["dh"]`` and
+    returns no gradient for ``hidden`` itself; this backward writes its rows into that buffer and returns it as THE
+    gradient of ``hidden``.  Autograd therefore sees one ordinary contribution (no assumption about which buffer it
+    keeps, views / CopySlices and further consumers of ``hidden`` included: ADVICE r3)."""
 
     @staticmethod
     def forward(ctx, hidden, pos: int, side: int, link=None):
@@ -1306,6 +1312,8 @@ class GatherQueryRowsFn(torch.autograd.Function):
         k_copy_rows(hidden.view(-1)[pos * H:], hook_row_map(S, H, side), out, L.identity_map(H), B * side * side, H)
         ctx.cfg = (B, S, H, pos, side)
         ctx.link = link
+        if link is not None:
+            link["armed"] = bool(ctx.needs_input_grad[0])  # this node's backward will run iff the scatter's does
         return out
 
     @staticmethod
@@ -1313,10 +1321,10 @@ class GatherQueryRowsFn(torch.autograd.Function):
         B, S, H, pos, side = ctx.cfg
         g = g.contiguous()
         dh = ctx.link.pop("dh", None) if ctx.link is not None else None
-        if dh is not None and dh.dtype == g.dtype:
-            k_copy_rows(g, L.identity_map(H), dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)
-            return None, None, None, None
-        dh = torch.zeros((B, S, H), dtype=g.dtype, device=g.device)
+        if dh is None:
+            dh = torch.zeros((B, S, H), dtype=g.dtype, device=g.device)
+        elif dh.dtype != g.dtype:
+            g = g.to(dh.dtype)
         k_copy_rows(g, L.identity_map(H), dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)
         return dh, None, None, None
 
@@ -1344,8 +1352,9 @@ class ScatterQueryRowsFn(torch.autograd.Function):
         k_copy_rows(g.view(-1)[pos * H:], hook_row_map(S, H, side), drows, L.identity_map(H), B * side * side, H)
         dh = g.clone()
         k_copy_rows(None, None, dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)  # zero the rows
-        if ctx.link is not None and ctx.needs_input_grad[0]:
-            ctx.link["dh"] = dh
+        if ctx.link is not None and ctx.link.get("armed") and ctx.needs_input_grad[0]:
+            ctx.link["dh"] = dh  # the paired gather's backward completes it and returns it for `hidden`
+            return None, drows, None, None, None
         return dh, drows, None, None, None
 
 

@@ -44,6 +44,7 @@ class _ZBucket:
         self.grad_shard = torch.zeros(self.shard_len, device=dev, dtype=dt)
         self.pending = len(params)
         self.work = None
+        self.dirty = False  # flat_grad holds something since it was last zeroed (set by every accumulation)
 
 
 class Zero2AdamW:
@@ -95,6 +96,7 @@ class Zero2AdamW:
             raise RuntimeError("Zero2AdamW: a gradient arrived after this step's reduce-scatter was launched; run every "
                                "micro-batch but the last one of a step under `with opt.no_sync():`")
         b.grad_views[i].add_(p.grad)  # accumulate (flat_grad is zeroed by step())
+        b.dirty = True
         p.grad = None  # the full gradient is not kept: ZeRO-2 holds 1/world of it after the reduce-scatter
         if not self._sync:
             return
@@ -126,6 +128,7 @@ class Zero2AdamW:
                 for i, p in enumerate(b.params):
                     if p.grad is not None:
                         b.grad_views[i].add_(p.grad)
+                        b.dirty = True
                         p.grad = None
                 self._launch(b)
             if b.work is not None:
@@ -137,6 +140,7 @@ class Zero2AdamW:
             if self.world > 1:
                 gathers.append(dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=self.group, async_op=True))
             b.flat_grad.zero_()
+            b.dirty = False
             b.pending = len(b.params)
         for w in gathers:
             w.wait()
@@ -149,8 +153,9 @@ class Zero2AdamW:
             if b.work is not None:       # a launched reduce-scatter must finish before its buffers are reused
                 b.work.wait()
                 b.work = None
-            if b.pending != len(b.params) or self.world == 1:
+            if b.dirty:                  # `pending` does not move under no_sync(): the flag is set by every accumulation
                 b.flat_grad.zero_()
+                b.dirty = False
             b.pending = len(b.params)
             for p in b.params:
                 p.grad = None

@@ -137,3 +137,53 @@ def test_zero2_skipped_step_leaves_no_stale_gradients():
     o2.step()
     for a, b in zip(m.parameters(), m2.parameters()):
         assert torch.allclose(a, b, atol=1e-7, rtol=1e-6)
+
+
+def _worker_skipped(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cambrian_amd.train.dp import init_distributed
+    from cambrian_amd.train.zero import Zero2AdamW
+    init_distributed("gloo")
+    m = _model()
+    params = list(m.parameters())
+    opt = Zero2AdamW(params, lr=1e-2, weight_decay=0.1, bucket_mb=0.002)
+    with opt.no_sync():                                     # a micro-batch whose step is then skipped: `pending` never moved
+        (m(_data(world, 7)[rank]).pow(2).mean() * 1e3).backward()
+    opt.zero_grad()
+    (m(_data(world, 8)[rank]).pow(2).mean() * 1e3).backward()   # a launched reduce-scatter that is then dropped
+    opt.zero_grad()
+    m(_data(world, 0)[rank]).pow(2).mean().backward()
+    opt.step()
+    opt.zero_grad()
+    m2 = _model()                                            # unsharded AdamW on the rank-averaged gradients of step 0 only
+    p2 = list(m2.parameters())
+    grads = None
+    for k in range(world):
+        for p in p2:
+            p.grad = None
+        m2(_data(world, 0)[k]).pow(2).mean().backward()
+        g = [p.grad.clone() for p in p2]
+        grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+    for p, g in zip(p2, grads):
+        p.grad = g / world
+    torch.optim.AdamW(p2, lr=1e-2, weight_decay=0.1).step()
+    ok = all(torch.allclose(a.detach(), b.detach(), atol=1e-6, rtol=1e-5) for a, b in zip(params, p2))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero2_world2_skipped_no_sync_step_leaves_no_stale_gradients():
+    """at world > 1 a zero_grad() after a no_sync() micro-batch (whose backward adds into flat_grad without
+    moving `pending`) must still clear the bucket: the next step's reduce-scatter carries only its own gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_skipped, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
