@@ -6,6 +6,7 @@
 // own consecutive channel groups, so every load is a coalesced run along C.  Each thread produces a
 // strip of XT outputs along x and reuses the XT+6 input vectors of a row for all 7 horizontal taps:
 // (XT+6)*7 / XT = 17.5 vector loads per output instead of 49.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -161,6 +162,148 @@ __global__ void __launch_bounds__(256) dwconv7x7_lds_kernel(const T* __restrict_
   }
 }
 
+// ---- column-walking variant (C % 64 == 0): round 4 ---------------------------------------------------------------
+// The LDS kernel above is VALU-bound and almost half of its vector instructions are not multiply-adds: per tap row a
+// thread converts 10 bf16x8 input vectors to fp32 (80 shift / mask operations) for 112 v_pk_fma_f32, and reads 7 fp32 weight
+// vectors from LDS (1.8-2.0 TB/s = 0.24 of the HBM peak, profiles/r03_hbm_kernels_table.md).  Here a lane owns ONE
+// channel pair — the natural operand of v_pk_fma_f32 — and a strip of XT = 4 outputs along x, and WALKS DOWN the rows of
+// its chunk:
+//   * the 49 x 2 tap weights of its channel pair live in 98 registers for the whole walk (no LDS, no weight traffic);
+//   * an input row is loaded (10 dwords per lane, a wave's 32 channel pairs = one whole 128-byte line per position) and
+//     converted ONCE, then feeds the 7 output rows it belongs to: 20 conversions per 196 v_pk_fma_f32 instead of 80 per 112;
+//   * the 7 output rows in flight are 7 accumulator slots (7 x 4 x 2 registers); output row o sits in slot o % 7, so with
+//     the row loop unrolled by 7 every slot index is a compile-time constant; a row leaves when its 7th input row is in.
+// No LDS, no barriers.  A wave = 32 channel pairs x 2 adjacent strips; a workgroup = 4 waves = 32 consecutive outputs of
+// one row chunk (neighbouring strips re-read 6 of their 10 positions: L1 / L2 hits).  The accumulation order per output
+// element (tap rows ascending, taps ascending, fp32 fma) is that of the kernels above: results are bit-identical.
+template <typename T> struct Pair;   // two consecutive channels of one position -> two floats
+template <> struct Pair<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[2]) {
+    const uint32_t r = *reinterpret_cast<const uint32_t*>(p);
+    v[0] = __uint_as_float(r << 16);
+    v[1] = __uint_as_float(r & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[2]) {
+    typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+    typedef float f32x2_v __attribute__((ext_vector_type(2)));
+    const f32x2_v f = {v[0], v[1]};
+    *reinterpret_cast<uint32_t*>(p) = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_v));
+  }
+};
+template <> struct Pair<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
+    const float2 r = *reinterpret_cast<const float2*>(p);
+    v[0] = r.x; v[1] = r.y;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) dwconv7x7_col_kernel(const T* __restrict__ x, int H, int W, int C,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            T* __restrict__ y, int chunk_rows, int n_chunks, int xblocks) {
+  constexpr int XT = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // blockIdx.x = ((b * n_chunks + chunk) * (C / 64) + cgroup) * xblocks + xblock;  32 outputs along x per workgroup
+  int bid = blockIdx.x;
+  const int xb = bid % xblocks; bid /= xblocks;
+  const int cg = bid % (C >> 6); bid /= (C >> 6);
+  const int chunk = bid % n_chunks;
+  const int64_t b = bid / n_chunks;
+  const int c = cg * 64 + 2 * (lane & 31);
+  const int x0 = xb * 32 + wave * 8 + (lane >> 5) * XT;
+  const int y0 = chunk * chunk_rows;
+  const int rows_out = (H - y0 < chunk_rows) ? (H - y0) : chunk_rows;
+  const T* xb_ = x + b * (int64_t)H * W * C + c;
+  T* yb_ = y + b * (int64_t)H * W * C + c;
+
+  float wt[49][2];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) {
+    const float2 r = *reinterpret_cast<const float2*>(w + (int64_t)t * C + c);
+    wt[t][0] = r.x; wt[t][1] = r.y;
+  }
+  const float2 bs = *reinterpret_cast<const float2*>(bias + c);
+  float acc[7][XT][2];
+#pragma unroll
+  for (int s_ = 0; s_ < 7; ++s_)
+#pragma unroll
+    for (int o = 0; o < XT; ++o) { acc[s_][o][0] = bs.x; acc[s_][o][1] = bs.y; }
+
+  // per-lane column offsets of the strip's 10 input positions (clamped; `ok` masks the zero padding)
+  int64_t coff[XT + 6];
+  bool cok[XT + 6];
+#pragma unroll
+  for (int k = 0; k < XT + 6; ++k) {
+    const int ix = x0 + k - 3;
+    cok[k] = ix >= 0 && ix < W;
+    coff[k] = (int64_t)(cok[k] ? ix : 0) * C;
+  }
+  const int n_in = rows_out + 6;   // input rows y0 - 3 .. y0 + rows_out + 2, j = 0 .. n_in - 1
+  auto phase = [&](int j, auto ph_c) {
+    constexpr int ph = decltype(ph_c)::value;   // j % 7
+    const int iy = y0 - 3 + j;
+    if (iy >= 0 && iy < H) {                    // wave-uniform: rows of the zero padding contribute nothing
+      float in[XT + 6][2];
+      const T* row = xb_ + (int64_t)iy * W * C;
+#pragma unroll
+      for (int k = 0; k < XT + 6; ++k) {
+        Pair<T>::load(row + coff[k], in[k]);
+        if (!cok[k]) { in[k][0] = 0.f; in[k][1] = 0.f; }
+      }
+#pragma unroll
+      for (int dy = 0; dy < 7; ++dy) {
+        const int o = j - dy;                   // the output row (chunk-local) this input row is tap row dy of
+        if (o >= 0 && o < rows_out) {           // wave-uniform
+          constexpr int dummy = 0; (void)dummy;
+          const int slot_c = (ph - dy + 7) % 7; // == o % 7, a constant per (ph, dy) once the loop is unrolled
+#pragma unroll
+          for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+            for (int q = 0; q < XT; ++q) {
+              acc[slot_c][q][0] += wt[dy * 7 + dx][0] * in[q + dx][0];
+              acc[slot_c][q][1] += wt[dy * 7 + dx][1] * in[q + dx][1];
+            }
+        }
+      }
+    }
+    const int done = j - 6;                     // tap row 6 of output row j - 6 was this input row: that row is complete
+    constexpr int dslot = (ph + 1) % 7;         // (ph - 6 + 7) % 7
+    if (done >= 0 && done < rows_out) {
+      T* orow = yb_ + ((int64_t)(y0 + done) * W) * C;
+#pragma unroll
+      for (int q = 0; q < XT; ++q)
+        if (x0 + q < W) Pair<T>::store(orow + (int64_t)(x0 + q) * C, acc[dslot][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < XT; ++q) { acc[dslot][q][0] = bs.x; acc[dslot][q][1] = bs.y; }
+  };
+  for (int j0 = 0; j0 < n_in; j0 += 7) {
+    phase(j0 + 0, std::integral_constant<int, 0>{});
+    if (j0 + 1 < n_in) phase(j0 + 1, std::integral_constant<int, 1>{});
+    if (j0 + 2 < n_in) phase(j0 + 2, std::integral_constant<int, 2>{});
+    if (j0 + 3 < n_in) phase(j0 + 3, std::integral_constant<int, 3>{});
+    if (j0 + 4 < n_in) phase(j0 + 4, std::integral_constant<int, 4>{});
+    if (j0 + 5 < n_in) phase(j0 + 5, std::integral_constant<int, 5>{});
+    if (j0 + 6 < n_in) phase(j0 + 6, std::integral_constant<int, 6>{});
+  }
+}
+
+template <typename T>
+int launch_dwconv_col(const void* x, int64_t B, int H, int W, int C, const float* w, const float* bias, void* y,
+                      int chunk_rows, hipStream_t s) {
+  const int n_chunks = (H + chunk_rows - 1) / chunk_rows;
+  const int xblocks = (W + 31) / 32;
+  const int64_t grid = B * n_chunks * (C / 64) * (int64_t)xblocks;
+  if (grid > 0x7fffffff) return CMB_ERR_SHAPE;
+  hipLaunchKernelGGL(dwconv7x7_col_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, (const T*)x, H, W, C, w, bias, (T*)y,
+                     chunk_rows, n_chunks, xblocks);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
 template <typename T>
 int launch_dwconv_lds(const void* x, int64_t B, int H, int W, int C, const float* w, const float* bias, void* y,
                       hipStream_t s) {
@@ -256,6 +399,14 @@ extern "C" int cmb_dwconv7x7_nhwc(int dtype, const void* x, int64_t B, int64_t H
   int64_t blocks = (total + 255) / 256;
   if (blocks > 65535) blocks = 65535;
   hipStream_t s = (hipStream_t)stream;
+  const int variant = cmb_knob(CMB_KNOB_DWCONV);
+  if (variant != 0 && (C & 63) == 0 && cmb_aligned16(x) && cmb_aligned16(y) && cmb_aligned16(w) && cmb_aligned16(bias)) {
+    // column-walking kernel; knob value = rows per chunk (1 -> 32): fewer rows = more waves, more halo rows re-read
+    const int chunk = variant == 1 ? 32 : variant;
+    if (dtype == CMB_BF16) return launch_dwconv_col<bf16_t>(x, B, (int)H, (int)W, (int)C, w, bias, y, chunk, s);
+    if (dtype == CMB_F32) return launch_dwconv_col<float>(x, B, (int)H, (int)W, (int)C, w, bias, y, chunk, s);
+    return CMB_ERR_BAD_ARG;
+  }
   if ((C & 63) == 0 && B <= 65535 && cmb_aligned16(x) && cmb_aligned16(y)) {
     if (dtype == CMB_BF16) return launch_dwconv_lds<bf16_t>(x, B, (int)H, (int)W, (int)C, w, bias, y, s);
     if (dtype == CMB_F32) return launch_dwconv_lds<float>(x, B, (int)H, (int)W, (int)C, w, bias, y, s);

@@ -552,3 +552,11 @@ extern "C" int cmb_resample_bilinear(int dtype, const void* in, int64_t B, int32
 
 extern "C" const char* cmb_version(void) { return "cambrian_amd 0.1.0 gfx950"; }
 extern "C" int cmb_abi_version(void) { return CMB_ABI_VERSION; }
+
+int g_cmb_knobs[CMB_KNOB_COUNT] = {CMB_KNOB_DEFAULTS};
+extern "C" int cmb_knob_set(int32_t knob, int32_t value) {
+  if (knob < 0 || knob >= CMB_KNOB_COUNT) return CMB_ERR_BAD_ARG;
+  g_cmb_knobs[knob] = value;
+  return CMB_OK;
+}
+extern "C" int cmb_knob_get(int32_t knob) { return (knob < 0 || knob >= CMB_KNOB_COUNT) ? -1 : g_cmb_knobs[knob]; }

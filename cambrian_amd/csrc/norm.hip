@@ -105,6 +105,119 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm forward, affine, no position table (the towers' LayerNorms: ViT blocks, ConvNeXt blocks): round 4.
+// The kernel above re-loads gamma and beta (2 x 4 D bytes of fp32) for every 2 D-byte row once D > 1024 — four times
+// the row's own bytes through the vector cache — and walks its rows one load -> reduce -> store round trip at a time
+// (3.6-4.0 TB/s on ConvNeXt stage 3 against 5+ for the path's other streaming kernels, profiles/r03_hbm_kernels_table.md).
+// Here the parameters are staged in LDS once per workgroup, and a wave keeps the NEXT row's loads in flight (raw 16-byte
+// vectors in registers) while it reduces and writes the current one.  Arithmetic and summation order are those of
+// layernorm_fwd_kernel: the two kernels are bit-identical (tests/test_kernels_gpu.py).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  bf16x8_t v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8_t*>(p); }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+};
+template <> struct Raw8<float> {
+  f32x4_t a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4_t*>(p);
+    b = *reinterpret_cast<const f32x4_t*>(p + 4);
+  }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+  }
+};
+
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) layernorm_fwd_lds_kernel(
+    const T* __restrict__ x, int64_t rows, int D, int64_t ldx, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out) {
+  extern __shared__ __attribute__((aligned(16))) float ln_sm[];  // gamma[D] then beta[D]
+  const int lane = threadIdx.x & 63;
+  const int nvec = D >> 3;
+  for (int i = threadIdx.x; i < nvec; i += 256) {
+    float g8[8], b8[8];
+    load8f(gamma + i * 8, g8);
+    load8f(beta + i * 8, b8);
+    Vec8<float>::store(ln_sm + i * 8, g8);
+    Vec8<float>::store(ln_sm + D + i * 8, b8);
+  }
+  __syncthreads();
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  Raw8<T> cur[NCH], nxt[NCH];
+  int64_t row = wave_global;
+  if (row < rows) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) cur[c].load(x + row * ldx + vi * 8);
+    }
+  }
+  for (; row < rows; row += nwaves) {
+    const int64_t nrow = row + nwaves;
+    if (nrow < rows) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int vi = lane + c * 64;
+        if (vi < nvec) nxt[c].load(x + nrow * ldx + vi * 8);
+      }
+    }
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        cur[c].get(v[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[c][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[c][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    T* yr = y + row * ldy;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        float o[8], g8[8], b8[8];
+        load8f(ln_sm + vi * 8, g8);
+        load8f(ln_sm + D + vi * 8, b8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g8[e] + b8[e];
+        Vec8<T>::store(yr + vi * 8, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  Rows are enumerated window-major so that all rows a block touches share one
 // position-table row: blockIdx.y = pos (0..grid_r^2-1), and "window" w enumerates
 // (b, qy, qx); token row = b*side^2 + (qy*grid_r+py)*side + qx*grid_r+px.  With grid_r == 1 this
@@ -522,6 +635,19 @@ int ln_fwd(const void* x, int64_t rows, int64_t D, int64_t ldx, const float* add
            const float* gamma, const float* beta, float eps, void* y, int64_t ldy, float* mean, float* rstd,
            hipStream_t s) {
   const int nch = nch_for(D);
+  const int variant = cmb_knob(CMB_KNOB_LN_FWD);
+  if (gamma && !add && variant != 0) {
+    // the towers' affine LayerNorms: parameters in LDS, next row in flight (layernorm_fwd_lds_kernel)
+    const int64_t cap = variant == 2 ? 4096 : variant == 3 ? 8192 : variant == 4 ? 1024 : 2048;
+    int64_t blocks = (rows + 7) / 8;  // >= 2 rows per wave, so that the prefetch has something to fetch
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const size_t smem = (size_t)2 * D * sizeof(float);
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_fwd_lds_kernel<T, NCH>), dim3((unsigned)blocks), dim3(256), smem, s,
+                                         (const T*)x, rows, (int)D, ldx, gamma, beta, eps, (T*)y, ldy, mean, rstd));
+    CMB_CHECK_LAUNCH();
+    return CMB_OK;
+  }
   // (a grid capped at the resident-wave capacity, 2048 workgroups, so that a wave walks more rows per parameter load was
   // measured SLOWER: 152 vs 126 us on 147456 x 1024 — fewer waves per CU hide less of the one-row-at-a-time latency)
   DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3(row_grid(rows)), dim3(256), 0, s,

@@ -17,8 +17,11 @@
 
 namespace {
 
-template <int HD>
-__global__ void __launch_bounds__(256) vit_attn_bf16_kernel(const bf16_t* __restrict__ qkv, int N, int heads,
+// WPE: waves per SIMD the register allocator must make room for (1 = whatever the kernel needs: 3 for head_dim 64, 2-3 for
+// 96); DB: two LDS tile buffers, ONE barrier per key tile (the next tile is stored into the buffer the previous iteration
+// read, which every wave left at that iteration's barrier) instead of two.
+template <int HD, int WPE, bool DB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) vit_attn_bf16_kernel(const bf16_t* __restrict__ qkv, int N, int heads,
                                                             float scale_log2e, bf16_t* __restrict__ out) {
   constexpr int KS = HD / 16;   // MFMA k-steps of QK^T
   constexpr int DT = HD / 32;   // 32-wide output tiles along d
@@ -28,8 +31,8 @@ __global__ void __launch_bounds__(256) vit_attn_bf16_kernel(const bf16_t* __rest
   constexpr int K_IT = (64 * KV8) / 256;
   constexpr int V_TASKS = 32 * KV8;
   constexpr int V_IT = (V_TASKS + 255) / 256;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDK];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[HD * LDV];
+  __shared__ __attribute__((aligned(16))) bf16_t sK_[(DB ? 2 : 1) * 64 * LDK];
+  __shared__ __attribute__((aligned(16))) bf16_t sV_[(DB ? 2 : 1) * HD * LDV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
@@ -71,7 +74,9 @@ __global__ void __launch_bounds__(256) vit_attn_bf16_kernel(const bf16_t* __rest
       }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    bf16_t* sK = sK_ + buf * 64 * LDK;
+    bf16_t* sV = sV_ + buf * HD * LDV;
 #pragma unroll
     for (int i = 0; i < K_IT; ++i) {
       const int id = tid + 256 * i, key = id / KV8, cv = id - key * KV8;
@@ -99,14 +104,17 @@ __global__ void __launch_bounds__(256) vit_attn_bf16_kernel(const bf16_t* __rest
   for (int d = 0; d < DT; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY;
+  f32x2_t l2 = {0.f, 0.f};   // the row sum as two partial sums: v_pk_add_f32 (round 4: the kernel is VALU-bound in the softmax)
 
   const int nt = (N + 63) / 64;
   load_tile(0);
-  store_tile();
+  store_tile(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) load_tile(t + 1);  // in flight while this tile is consumed
+    const bf16_t* sK = sK_ + (DB ? (t & 1) : 0) * 64 * LDK;
+    const bf16_t* sV = sV_ + (DB ? (t & 1) : 0) * HD * LDV;
 
     f32x16_t s[2];
 #pragma unroll
@@ -140,21 +148,26 @@ __global__ void __launch_bounds__(256) vit_attn_bf16_kernel(const bf16_t* __rest
     const float m_new = fmaxf(m, mx);
     if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
       const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-      l *= alpha;
+      l2 *= alpha;
 #pragma unroll
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
     }
     m = m_new;
+    {
+      const f32x2_t sc2 = {scale_log2e, scale_log2e}, mn2 = {-m_new, -m_new};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], scale_log2e, -m_new));
-        l += pv;
-        s[kt][r] = pv;
-      }
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t a = __builtin_elementwise_fma((f32x2_t){s[kt][r], s[kt][r + 1]}, sc2, mn2);
+          const f32x2_t pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          l2 += pv;
+          s[kt][r] = pv[0];
+          s[kt][r + 1] = pv[1];
+        }
+    }
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int kt = kb >> 1, hh = kb & 1;
@@ -171,11 +184,17 @@ __global__ void __launch_bounds__(256) vit_attn_bf16_kernel(const bf16_t* __rest
         acc_o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc_o[d], 0, 0, 0);
       }
     }
-    __syncthreads();
-    if (t + 1 < nt) store_tile();
-    __syncthreads();
+    if constexpr (DB) {
+      if (t + 1 < nt) store_tile((t + 1) & 1);
+      __syncthreads();
+    } else {
+      __syncthreads();
+      if (t + 1 < nt) store_tile(0);
+      __syncthreads();
+    }
   }
 
+  const float l = l2[0] + l2[1];
   const float l_tot = l + __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l_tot;
   const int q = q0 + j;
@@ -241,12 +260,22 @@ extern "C" int cmb_vit_attn_fwd(int dtype, const void* qkv, int64_t B, int64_t N
   if (dtype == CMB_BF16 && !force_simple && (hd == 64 || hd == 96)) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)heads, (unsigned)B);
     const float sl2 = scale * 1.4426950408889634f;
-    if (hd == 64)
-      hipLaunchKernelGGL(vit_attn_bf16_kernel<64>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (int)N, heads, sl2,
-                         (bf16_t*)out);
-    else
-      hipLaunchKernelGGL(vit_attn_bf16_kernel<96>, grid, dim3(256), 0, s, (const bf16_t*)qkv, (int)N, heads, sl2,
-                         (bf16_t*)out);
+    // CMB_KNOB_VIT_ATTN: 0 = round 3's structure (two barriers per tile, registers as needed); 1 = one barrier per tile
+    // (double-buffered LDS); 2 = 1 + registers capped for 4 (head_dim 64) / 3 (96) waves per SIMD
+    const int variant = cmb_knob(CMB_KNOB_VIT_ATTN);
+#define VIT_LAUNCH(HD_, WPE_, DB_)                                                                                  \
+  hipLaunchKernelGGL((vit_attn_bf16_kernel<HD_, WPE_, DB_>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (int)N, heads, sl2, \
+                     (bf16_t*)out)
+    if (hd == 64) {
+      if (variant == 2) VIT_LAUNCH(64, 4, true);
+      else if (variant == 1) VIT_LAUNCH(64, 1, true);
+      else VIT_LAUNCH(64, 1, false);
+    } else {
+      if (variant == 2) VIT_LAUNCH(96, 3, true);
+      else if (variant == 1) VIT_LAUNCH(96, 1, true);
+      else VIT_LAUNCH(96, 1, false);
+    }
+#undef VIT_LAUNCH
   } else {
     int64_t blocks = (B * heads * N + 3) / 4;
     if (blocks > 65535) blocks = 65535;

@@ -24,7 +24,8 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
-ABI_VERSION = 4   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
+KNOB_LN_FWD, KNOB_DWCONV, KNOB_GELU, KNOB_VIT_ATTN = 0, 1, 2, 3   # enum cmb_knob_id
+ABI_VERSION = 5   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
           -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
@@ -113,6 +114,8 @@ _i32, _i64, _f, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     "cmb_version": (C.c_char_p, []),
     "cmb_abi_version": (C.c_int, []),
+    "cmb_knob_set": (C.c_int, [_i32, _i32]),
+    "cmb_knob_get": (C.c_int, [_i32]),
     "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
     "cmb_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), _p]),
     "cmb_gemm_tile": (C.c_int, [C.c_int, _i64, _i64, _i32, _i32]),
@@ -187,6 +190,12 @@ def load() -> C.CDLL:
             raise CambrianAmdError(
                 f"{LIB_PATH} reports ABI revision {got}, this binding is written against {ABI_VERSION}: every symbol of a "
                 "stale build still resolves but argument lists have shifted — rebuild it (`make -C cambrian_amd/csrc`)")
+        # A/B runs: CAMBRIAN_AMD_KNOBS="<knob>=<value>,..." (enum cmb_knob_id) overrides the library's kernel-selection
+        # defaults for this process
+        for item in filter(None, os.environ.get("CAMBRIAN_AMD_KNOBS", "").split(",")):
+            k, v = item.split("=")
+            if lib.cmb_knob_set(int(k), int(v)) != 0:
+                raise CambrianAmdError(f"CAMBRIAN_AMD_KNOBS: unknown knob {k}")
         _lib = lib
     return _lib
 
@@ -225,3 +234,12 @@ def identity_map(ld: int) -> RowMap:
 
 def make_map(n1: int, n2: int, s0: int, s1: int, s2: int) -> RowMap:
     return RowMap(n1, n2, s0, s1, s2)
+
+
+def knob_set(knob: int, value: int) -> None:
+    """cmb_knob_set: which of several equivalent kernels an entry point launches (include/cambrian_amd.h)."""
+    check(load().cmb_knob_set(knob, value), "cmb_knob_set")
+
+
+def knob_get(knob: int) -> int:
+    return load().cmb_knob_get(knob)

@@ -57,11 +57,27 @@ typedef struct cmb_rowmap {
 /* library / build identification ("cambrian_amd <version> gfx950"). */
 const char* cmb_version(void);
 /* ABI revision: bumped whenever an entry point's signature or a descriptor's layout changes (round 2's key_valid
- * arguments = 2, round 3's fold_kv workspace = 3, the batch fields of cmb_gemm_desc = 4).  Bindings must compare it with the revision they
+ * arguments = 2, round 3's fold_kv workspace = 3, the batch fields of cmb_gemm_desc = 4,
+ * the kernel-selection knobs of round 4 = 5).  Bindings must compare it with the revision they
  * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
  * library still resolves, and a shifted argument list corrupts memory instead of failing. */
-#define CMB_ABI_VERSION 4
+#define CMB_ABI_VERSION 5
 int cmb_abi_version(void);
+
+/* Run-time kernel-selection knobs: which of several kernels that compute the SAME function an entry point launches
+ * (value 0 = the earlier kernel, kept for A/B runs; CMB_KNOB_DEFAULTS = what the library uses unless told otherwise).
+ * Meant for same-process A/B measurements (tools/r04_lab.py, bench.py's `ab` block) and start-up calibration; none
+ * changes an entry point's contract.  Not thread-safe against concurrent launches: set between steps.
+ *   CMB_KNOB_LN_FWD     cmb_layernorm_fwd, affine rows without a position table: 0 = one row per wave at a time,
+ *                       parameters re-read per row; 1..4 = parameters staged in LDS + next row prefetched (grid cap
+ *                       2048 / 4096 / 8192 / 1024 workgroups)
+ *   CMB_KNOB_DWCONV     cmb_dwconv7x7_nhwc (C % 64 == 0): 0 = one output row per thread; 1 = two output rows per thread
+ *   CMB_KNOB_GELU       bf16 GEMM epilogues' erf-GELU: 0 = Abramowitz-Stegun 7.1.26 (rcp + exp); 1 = relu(x) - |x| 2^P(|x|)
+ *   CMB_KNOB_VIT_ATTN   cmb_vit_attention: 0 = 32 queries per wave; 1 = 64 queries per wave */
+enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_GELU = 2, CMB_KNOB_VIT_ATTN = 3, CMB_KNOB_COUNT = 8 };
+#define CMB_KNOB_DEFAULTS 0, 0, 0, 0, 0, 0, 0, 0
+int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
+int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 
 /* ------------------------------------------------------------------------------------------
  * GEMM   C[M,N] = epilogue( alpha * A[M,K] · B[N,K]^T )            (nn.Linear layout)

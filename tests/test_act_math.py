@@ -69,3 +69,36 @@ def test_cmb_gelu_erf_fast_within_bf16_rounding():
     err = np.abs(got - ref)
     assert err.max() < 6e-7, err.max()
     assert (err / np.maximum(np.abs(ref), 1e-3)).max() < 3e-4
+
+
+def test_cmb_gelu_erf_v2_within_bf16_rounding():
+    """Round 4's epilogue GELU (common.h::cmb_gelu_erf_v2: relu(x) - t 2^P(t), t = min(|x|, 16)), coefficients parsed from the
+    header and evaluated in float32: absolute error <= 6e-7, relative error <= 1e-5 wherever |GELU| > 1e-3, against the
+    exact-erf GELU of the reference (nn.GELU(), vision_sampler.py:241); P stays decreasing up to the clamp, so large inputs
+    cannot turn the 2^P term back on; infinities stay finite / signed as GELU's limits."""
+    src = open(os.path.join(ROOT, "cambrian_amd", "csrc", "common.h")).read()
+    body = src[src.index("float cmb_gelu_erf_v2(float x)"):]
+    body = body[:body.index("return fmaf(-t")]
+    clamp = float(re.search(r"fminf\(fabsf\(x\), (\d+\.\d+)f\)", body).group(1))
+    nums = [float(x.rstrip("f")) for x in re.findall(r"-?\d\.\d+(?:e-\d+)?f", body.split("float p =")[1])]
+    assert len(nums) == 8 and clamp == 16.0
+    # the pair form the GEMM epilogue calls carries the same numbers
+    pair = src[src.index("void cmb_gelu_erf_v2_pair"):]
+    pair = pair[:pair.index("const f32x2_t h =")]
+    for c in nums:
+        assert pair.count(repr(c)) >= 2 or pair.count(("%.16g" % c)) >= 2, c
+    f = np.float32
+    x = np.concatenate([np.linspace(-20, 20, 800001), np.random.default_rng(2).normal(size=200000) * 2]).astype(f)
+    t = np.minimum(np.abs(x), f(clamp)).astype(f)
+    p = np.full_like(x, f(nums[0]))
+    for k in nums[1:]:
+        p = (p.astype(np.float64) * t + np.float64(f(k))).astype(f)          # fmaf
+    h = np.exp2(p.astype(np.float64)).astype(f)
+    got = (np.maximum(x, f(0)).astype(np.float64) - t.astype(np.float64) * h).astype(f).astype(np.float64)
+    ref = np.array([0.5 * float(v) * (1.0 + math.erf(float(v) / math.sqrt(2.0))) for v in x])
+    err = np.abs(got - ref)
+    assert err.max() < 6e-7, err.max()
+    assert (err / np.maximum(np.abs(ref), 1e-3)).max() < 1e-5
+    tt = np.linspace(0, clamp, 200001)
+    P = np.polyval(nums, tt)
+    assert (np.diff(P) < 0).all() and P[-1] < -150
