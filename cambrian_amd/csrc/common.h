@@ -134,30 +134,16 @@ __device__ __forceinline__ float cmb_erf(float a) {
   return t > 0.927734375f ? big : small;
 }
 
-// GELU(x) = x * Phi(x) with Phi(-|x|) = 0.5 * erfc(|x| / sqrt 2) from the five-term rational form of Abramowitz & Stegun
-// 7.1.26 (|error of erf| <= 1.5e-7): 15 VALU operations per element against 25 for 0.5 x (1 + cmb_erf(x / sqrt 2)).  Used
-// by the bf16 GEMM epilogues, where the activation runs with the matrix pipe idle and the result is rounded to bf16:
-// absolute error <= 5e-7, relative error <= 2e-4 wherever |GELU| > 1e-3 (a bf16 ulp is 2e-3; tests/test_act_math.py
-// re-evaluates these coefficients in numpy).  The fp32 kernels and the stand-alone activation kernels keep cmb_erf.
-__device__ __forceinline__ float cmb_gelu_erf_fast(float x) {
-  const float t = cmb_rcp(fmaf(fabsf(x), 0.23164189f, 1.0f));  // 1 / (1 + 0.3275911 |x| / sqrt 2)
-  float q = 0.5307027145f;                                       // the A&S coefficients, halved
-  q = fmaf(q, t, -0.7265760135f);
-  q = fmaf(q, t, 0.7107068705f);
-  q = fmaf(q, t, -0.142248368f);
-  q = fmaf(q, t, 0.127414796f);
-  const float h = q * t * __builtin_amdgcn_exp2f(x * x * -0.72134752f);  // Phi(-|x|); -0.5 log2(e)
-  const float phi = x > 0.0f ? 1.0f - h : h;
-  return x * phi;
-}
-
-// Round 4: the same GELU with ONE quarter-rate instruction instead of two, in a form whose polynomial the compiler packs
-// into v_pk_fma_f32:   GELU(x) = relu(x) - t * Phi(-t),  t = min(|x|, 16),  Phi(-t) = 2^P(t)
+// The bf16 GEMM epilogues' exact-erf GELU (the activation runs with the matrix pipe idle and the result is rounded to bf16; the
+// fp32 kernels and the stand-alone activation kernels keep cmb_erf):
+//     GELU(x) = relu(x) - t * Phi(-t),  t = min(|x|, 16),  Phi(-t) = 2^P(t)
 // with P the degree-7 minimax fit of log2 Phi(-t) on [0, 6] (monotone decreasing to P(16) = -222, so the clamp only keeps
 // infinities finite).  |error| <= 5.1e-7 absolute, <= 4e-6 relative wherever |GELU| > 1e-3 (tests/test_act_math.py
-// re-evaluates these coefficients in numpy): per element 7 fma + min + max + fma + v_exp_f32 against 5 fma + 5 other
-// operations + v_rcp_f32 + v_exp_f32 above — the epilogue of the 4-wave GEMM pays every VALU cycle in full.
-__device__ __forceinline__ float cmb_gelu_erf_v2(float x) {
+// re-evaluates these coefficients in numpy).  Round 4: ONE quarter-rate instruction (v_exp_f32) and 7 fma + min + max + fma per
+// element; rounds 2-3 used Abramowitz-Stegun 7.1.26 (v_rcp_f32 AND v_exp_f32, 5 fma + 5 other operations): the epilogue of
+// the 4-wave GEMM pays every VALU cycle in full, ConvNeXt fc1 + GELU 989 -> 1060 TFLOP/s (profiles/r04_lab.md).  Every
+// operation is an explicit fma / min / max (no contraction left to the compiler), so all GEMM kernels agree bit for bit.
+__device__ __forceinline__ float cmb_gelu_erf_bf16(float x) {
   const float t = fminf(fabsf(x), 16.0f);
   float p = -1.6755886917962926e-06f;
   p = fmaf(p, t, 5.900045289308764e-05f);
@@ -169,10 +155,10 @@ __device__ __forceinline__ float cmb_gelu_erf_v2(float x) {
   p = fmaf(p, t, -0.9999958872795105f);
   return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
-// two elements at a time on 2-vectors: hipcc keeps the scalar form above as seven v_fmaak_f32 (literal constants) per
-// element; on vector operands the Horner steps become v_pk_fma_f32 — half the issue slots
+// the same, two elements at a time on 2-vectors (identical results): hipcc keeps the scalar form as seven v_fmaak_f32
+// (literal constants) per element; on vector operands the Horner steps become v_pk_fma_f32 — half the issue slots
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void cmb_gelu_erf_v2_pair(float& a, float& b) {
+__device__ __forceinline__ void cmb_gelu_erf_bf16_pair(float& a, float& b) {
   const f32x2_t t = {fminf(fabsf(a), 16.0f), fminf(fabsf(b), 16.0f)};
   f32x2_t p = {-1.6755886917962926e-06f, -1.6755886917962926e-06f};
   p = __builtin_elementwise_fma(p, t, (f32x2_t){5.900045289308764e-05f, 5.900045289308764e-05f});
@@ -188,7 +174,6 @@ __device__ __forceinline__ void cmb_gelu_erf_v2_pair(float& a, float& b) {
   a = o[0];
   b = o[1];
 }
-#define CMB_ACT_GELU_ERF_V2 5  /* internal template code (never in a descriptor): CMB_ACT_GELU_ERF through cmb_gelu_erf_v2 */
 
 __device__ __forceinline__ float act_apply(int act, float x) {
   switch (act) {

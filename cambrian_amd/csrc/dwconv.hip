@@ -178,8 +178,10 @@ __global__ void __launch_bounds__(256) dwconv7x7_lds_kernel(const T* __restrict_
 // element (tap rows ascending, taps ascending, fp32 fma) is that of the kernels above: results are bit-identical.
 template <typename T> struct Pair;   // two consecutive channels of one position -> two floats
 template <> struct Pair<bf16_t> {
-  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[2]) {
-    const uint32_t r = *reinterpret_cast<const uint32_t*>(p);
+  typedef uint32_t raw_t;
+  static __device__ __forceinline__ raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+  static __device__ __forceinline__ void unpack(raw_t r, bool ok, float (&v)[2]) {
+    r = ok ? r : 0u;
     v[0] = __uint_as_float(r << 16);
     v[1] = __uint_as_float(r & 0xffff0000u);
   }
@@ -191,9 +193,10 @@ template <> struct Pair<bf16_t> {
   }
 };
 template <> struct Pair<float> {
-  static __device__ __forceinline__ void load(const float* p, float (&v)[2]) {
-    const float2 r = *reinterpret_cast<const float2*>(p);
-    v[0] = r.x; v[1] = r.y;
+  typedef float2 raw_t;
+  static __device__ __forceinline__ raw_t load_raw(const float* p) { return *reinterpret_cast<const float2*>(p); }
+  static __device__ __forceinline__ void unpack(raw_t r, bool ok, float (&v)[2]) {
+    v[0] = ok ? r.x : 0.f; v[1] = ok ? r.y : 0.f;
   }
   static __device__ __forceinline__ void store(float* p, const float (&v)[2]) {
     *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
@@ -242,22 +245,30 @@ __global__ void __launch_bounds__(256) dwconv7x7_col_kernel(const T* __restrict_
     coff[k] = (int64_t)(cok[k] ? ix : 0) * C;
   }
   const int n_in = rows_out + 6;   // input rows y0 - 3 .. y0 + rows_out + 2, j = 0 .. n_in - 1
+  // The NEXT input row's 10 dwords are requested before the current row's 196 multiply-adds (a wave alone on its strip has
+  // nothing else to cover the round trip to L2 / HBM with: 2 waves per SIMD at 217 registers).
+  typename Pair<T>::raw_t cur[XT + 6], nxt[XT + 6];
+  auto fetch = [&](int j, typename Pair<T>::raw_t (&dst)[XT + 6]) {
+    const int iy = y0 - 3 + j;
+    if (j < n_in && iy >= 0 && iy < H) {        // wave-uniform
+      const T* row = xb_ + (int64_t)iy * W * C;
+#pragma unroll
+      for (int k = 0; k < XT + 6; ++k) dst[k] = Pair<T>::load_raw(row + coff[k]);
+    }
+  };
+  fetch(0, cur);
   auto phase = [&](int j, auto ph_c) {
     constexpr int ph = decltype(ph_c)::value;   // j % 7
     const int iy = y0 - 3 + j;
+    fetch(j + 1, nxt);
     if (iy >= 0 && iy < H) {                    // wave-uniform: rows of the zero padding contribute nothing
       float in[XT + 6][2];
-      const T* row = xb_ + (int64_t)iy * W * C;
 #pragma unroll
-      for (int k = 0; k < XT + 6; ++k) {
-        Pair<T>::load(row + coff[k], in[k]);
-        if (!cok[k]) { in[k][0] = 0.f; in[k][1] = 0.f; }
-      }
+      for (int k = 0; k < XT + 6; ++k) Pair<T>::unpack(cur[k], cok[k], in[k]);
 #pragma unroll
       for (int dy = 0; dy < 7; ++dy) {
         const int o = j - dy;                   // the output row (chunk-local) this input row is tap row dy of
         if (o >= 0 && o < rows_out) {           // wave-uniform
-          constexpr int dummy = 0; (void)dummy;
           const int slot_c = (ph - dy + 7) % 7; // == o % 7, a constant per (ph, dy) once the loop is unrolled
 #pragma unroll
           for (int dx = 0; dx < 7; ++dx)
@@ -269,6 +280,8 @@ __global__ void __launch_bounds__(256) dwconv7x7_col_kernel(const T* __restrict_
         }
       }
     }
+#pragma unroll
+    for (int k = 0; k < XT + 6; ++k) cur[k] = nxt[k];
     const int done = j - 6;                     // tap row 6 of output row j - 6 was this input row: that row is complete
     constexpr int dslot = (ph + 1) % 7;         // (ph - 6 + 7) % 7
     if (done >= 0 && done < rows_out) {
@@ -401,8 +414,8 @@ extern "C" int cmb_dwconv7x7_nhwc(int dtype, const void* x, int64_t B, int64_t H
   hipStream_t s = (hipStream_t)stream;
   const int variant = cmb_knob(CMB_KNOB_DWCONV);
   if (variant != 0 && (C & 63) == 0 && cmb_aligned16(x) && cmb_aligned16(y) && cmb_aligned16(w) && cmb_aligned16(bias)) {
-    // column-walking kernel; knob value = rows per chunk (1 -> 32): fewer rows = more waves, more halo rows re-read
-    const int chunk = variant == 1 ? 32 : variant;
+    // column-walking kernel; rows per chunk: fewer rows = more waves, more halo rows re-read (profiles/r04_lab.md)
+    const int chunk = variant == 1 ? (H >= 128 ? 64 : 32) : variant;
     if (dtype == CMB_BF16) return launch_dwconv_col<bf16_t>(x, B, (int)H, (int)W, (int)C, w, bias, y, chunk, s);
     if (dtype == CMB_F32) return launch_dwconv_col<float>(x, B, (int)H, (int)W, (int)C, w, bias, y, chunk, s);
     return CMB_ERR_BAD_ARG;

@@ -340,8 +340,7 @@ int launch_p5_act(GemmParams& p, int splits, hipStream_t s) {
 
 int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s) {
   switch (p.slabs ? CMB_ACT_NONE : p.act) {
-    case CMB_ACT_GELU_ERF:
-      return cmb_knob(CMB_KNOB_GELU) ? launch_p5_act<CMB_ACT_GELU_ERF_V2>(p, splits, s) : launch_p5_act<CMB_ACT_GELU_ERF>(p, splits, s);
+    case CMB_ACT_GELU_ERF: return launch_p5_act<CMB_ACT_GELU_ERF>(p, splits, s);
     case CMB_ACT_GELU_TANH: return launch_p5_act<CMB_ACT_GELU_TANH>(p, splits, s);
     case CMB_ACT_QUICK_GELU: return launch_p5_act<CMB_ACT_QUICK_GELU>(p, splits, s);
     case CMB_ACT_SILU: return launch_p5_act<CMB_ACT_SILU>(p, splits, s);

@@ -638,8 +638,10 @@ int ln_fwd(const void* x, int64_t rows, int64_t D, int64_t ldx, const float* add
   const int variant = cmb_knob(CMB_KNOB_LN_FWD);
   if (gamma && !add && variant != 0) {
     // the towers' affine LayerNorms: parameters in LDS, next row in flight (layernorm_fwd_lds_kernel)
-    const int64_t cap = variant == 2 ? 4096 : variant == 3 ? 8192 : variant == 4 ? 1024 : 2048;
-    int64_t blocks = (rows + 7) / 8;  // >= 2 rows per wave, so that the prefetch has something to fetch
+    // ~4 rows per wave: enough for the prefetch to run ahead, few enough that small launches still fill the chip
+    // (profiles/r04_lab.md: 2048 / 4096 / 8192 / 1024-workgroup caps per shape); knob values > 1 = an explicit cap
+    int64_t blocks = (rows + 15) / 16;
+    const int64_t cap = variant > 1 ? variant : 8192;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     const size_t smem = (size_t)2 * D * sizeof(float);

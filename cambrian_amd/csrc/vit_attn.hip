@@ -260,19 +260,17 @@ extern "C" int cmb_vit_attn_fwd(int dtype, const void* qkv, int64_t B, int64_t N
   if (dtype == CMB_BF16 && !force_simple && (hd == 64 || hd == 96)) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)heads, (unsigned)B);
     const float sl2 = scale * 1.4426950408889634f;
-    // CMB_KNOB_VIT_ATTN: 0 = round 3's structure (two barriers per tile, registers as needed); 1 = one barrier per tile
-    // (double-buffered LDS); 2 = 1 + registers capped for 4 (head_dim 64) / 3 (96) waves per SIMD
+    // CMB_KNOB_VIT_ATTN: 0 = round 3's structure (two barriers per tile); 1 = one barrier per tile (double-buffered LDS).
+    // (Capping the registers for 4 / 3 waves per SIMD spills 13 / 19 registers and measured 25-40 % slower: not kept.)
     const int variant = cmb_knob(CMB_KNOB_VIT_ATTN);
 #define VIT_LAUNCH(HD_, WPE_, DB_)                                                                                  \
   hipLaunchKernelGGL((vit_attn_bf16_kernel<HD_, WPE_, DB_>), grid, dim3(256), 0, s, (const bf16_t*)qkv, (int)N, heads, sl2, \
                      (bf16_t*)out)
     if (hd == 64) {
-      if (variant == 2) VIT_LAUNCH(64, 4, true);
-      else if (variant == 1) VIT_LAUNCH(64, 1, true);
+      if (variant == 1) VIT_LAUNCH(64, 1, true);
       else VIT_LAUNCH(64, 1, false);
     } else {
-      if (variant == 2) VIT_LAUNCH(96, 3, true);
-      else if (variant == 1) VIT_LAUNCH(96, 1, true);
+      if (variant == 1) VIT_LAUNCH(96, 1, true);
       else VIT_LAUNCH(96, 1, false);
     }
 #undef VIT_LAUNCH

@@ -69,13 +69,13 @@ int cmb_abi_version(void);
  * Meant for same-process A/B measurements (tools/r04_lab.py, bench.py's `ab` block) and start-up calibration; none
  * changes an entry point's contract.  Not thread-safe against concurrent launches: set between steps.
  *   CMB_KNOB_LN_FWD     cmb_layernorm_fwd, affine rows without a position table: 0 = one row per wave at a time,
- *                       parameters re-read per row; 1..4 = parameters staged in LDS + next row prefetched (grid cap
- *                       2048 / 4096 / 8192 / 1024 workgroups)
- *   CMB_KNOB_DWCONV     cmb_dwconv7x7_nhwc (C % 64 == 0): 0 = one output row per thread; 1 = two output rows per thread
- *   CMB_KNOB_GELU       bf16 GEMM epilogues' erf-GELU: 0 = Abramowitz-Stegun 7.1.26 (rcp + exp); 1 = relu(x) - |x| 2^P(|x|)
- *   CMB_KNOB_VIT_ATTN   cmb_vit_attention: 0 = 32 queries per wave; 1 = 64 queries per wave */
-enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_GELU = 2, CMB_KNOB_VIT_ATTN = 3, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 0, 0, 0, 0, 0, 0, 0, 0
+ *                       parameters re-read per row (rounds 1-3); 1 = parameters staged in LDS + next row prefetched,
+ *                       rows / 16 workgroups up to 8192; > 1 = the same with that workgroup cap
+ *   CMB_KNOB_DWCONV     cmb_dwconv7x7_nhwc (C % 64 == 0): 0 = LDS-tiled kernel (rounds 1-3); 1 = column-walking kernel with
+ *                       register-resident taps, 64 rows per chunk for maps of >= 128 rows, else 32; > 1 = that many rows per chunk
+ *   CMB_KNOB_VIT_ATTN   cmb_vit_attn_fwd (bf16): 0 = two barriers per key tile (round 3); 1 = two LDS tile buffers, one barrier */
+enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_COUNT = 8 };
+#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 0, 0, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 

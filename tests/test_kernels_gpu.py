@@ -532,3 +532,74 @@ def test_add_rmsnorm_fused(dev, name, dt, frozen):
     assert rel_err(xd.grad, xr.grad) < tol and torch.equal(xd.grad, dd.grad)
     if not frozen:
         assert rel_err(wd.grad, wr.grad) < (tol if name == "fp32" else 3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ kernel-selection knobs
+# cmb_knob_set picks between kernels that compute the SAME function (round 4): every pair is checked against each other here
+# and — through the tests above, which run with the library's defaults — against the fp32 restatement.
+@pytest.mark.parametrize("name,dt", DTYPES)
+@pytest.mark.parametrize("rows,D", [(1, 384), (7, 1536), (4099, 1536), (1000, 3072), (513, 1152), (2049, 4096), (300, 8192)])
+def test_layernorm_fwd_variants_bit_equal(dev, name, dt, rows, D):
+    """LDS-parameter / prefetching LayerNorm forward == the one-row-at-a-time kernel, bit for bit (same arithmetic and
+    summation order), statistics included, for row strides larger than D and row counts that leave ragged waves."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(rows + D)
+    x = _rand(g, rows, D + 8).to(dt).to(dev)[:, :D]
+    gamma, beta = (1 + 0.1 * _rand(g, D)).to(dev), (0.1 * _rand(g, D)).to(dev)
+    outs = []
+    try:
+        for var in (0, 1, 3):
+            L.knob_set(L.KNOB_LN_FWD, var)
+            outs.append(ops.k_layernorm_fwd(x, gamma, beta, 1e-6))
+    finally:
+        L.knob_set(L.KNOB_LN_FWD, 1)
+    for y, mean, rstd in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(mean, outs[0][1]) and torch.equal(rstd, outs[0][2])
+    ref = F.layer_norm(x.float().cpu(), (D,), gamma.cpu(), beta.cpu(), 1e-6)
+    assert rel_err(outs[1][0], ref) < TOL[name]
+
+
+@pytest.mark.parametrize("name,dt", DTYPES)
+@pytest.mark.parametrize("B,Hh,Ww,C", [(2, 13, 10, 128), (1, 32, 48, 192), (3, 7, 5, 64), (1, 70, 33, 64), (2, 64, 64, 128)])
+def test_dwconv7x7_variants_bit_equal(dev, name, dt, B, Hh, Ww, C):
+    """Column-walking depthwise conv (register-resident taps, rows in chunks of 32 / 64 / 5) == the LDS-tiled kernel, bit for
+    bit: same tap order per output element; ragged widths (partial strips, strips beyond the map), maps shorter than a chunk,
+    chunk boundaries inside the map."""
+    from cambrian_amd.model.multimodal_encoder import vit_ops
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(41 + C + Hh)
+    x = _rand(g, B, Hh, Ww, C).to(dt).to(dev)
+    w, b = _rand(g, C, 1, 7, 7, scale=0.1), _rand(g, C)
+    w49 = w.view(C, 49).T.contiguous().to(dev)
+    outs = []
+    try:
+        for var in (0, 1, 64, 5):
+            L.knob_set(L.KNOB_DWCONV, var)
+            outs.append(vit_ops.k_dwconv7x7(x, w49, b.to(dev)))
+    finally:
+        L.knob_set(L.KNOB_DWCONV, 1)
+    for y in outs[1:]:
+        assert torch.equal(y, outs[0])
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w, b, padding=3, groups=C).permute(0, 2, 3, 1)
+    assert rel_err(outs[1], ref) < TOL[name]
+
+
+@pytest.mark.parametrize("N,heads,hd", [(577, 16, 64), (730, 24, 64), (729, 16, 96), (64, 2, 64), (65, 1, 96)])
+def test_vit_attn_variants(dev, N, heads, hd):
+    """One-barrier (double-buffered) tower attention == the two-barrier kernel bit for bit (same instruction stream per tile),
+    and both against the fp32 one-wave-per-query kernel."""
+    from cambrian_amd.model.multimodal_encoder import vit_ops
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(N + hd)
+    B = 2
+    qkv = _rand(g, B * N, 3 * heads * hd).to(torch.bfloat16).to(dev)
+    outs = []
+    try:
+        for var in (0, 1):
+            L.knob_set(L.KNOB_VIT_ATTN, var)
+            outs.append(vit_ops.k_vit_attn(qkv, B, N, heads, hd, hd ** -0.5))
+    finally:
+        L.knob_set(L.KNOB_VIT_ATTN, 1)
+    assert torch.equal(outs[0], outs[1])
+    want = vit_ops.k_vit_attn(qkv.float(), B, N, heads, hd, hd ** -0.5)
+    assert rel_err(outs[1], want) < 1e-2
