@@ -316,11 +316,22 @@ def gemm_ab(dev, iters=20):
 PARITY = {
     "benched_dtype": "bf16 (fp32 accumulate / softmax / LayerNorm statistics; fp32 master parameters)",
     "oracle": "oracle/{sva,arch,llama,towers}.py: CPU fp32 restatement pinned to the real reference modules (tests/golden/)",
-    "logits_rel_err_vs_fp32_oracle": {"observed": "7.9e-3 .. 9.2e-3", "test_bound": 2e-2, "where": "tests/test_model_gpu.py, tools/probe_bf16_tolerance.py"},
-    "trainable_grad_rel_err_vs_fp32_oracle": {"observed_worst_tensor": "1.5e-2 .. 1.9e-2", "test_bound": 4e-2},
-    "systematic_error_checks": "least-squares slope |s - 1| < 5e-3 (logits) / 1e-2 (gradients), relative L2 < 1e-2 (tests/conftest.py::fit_err)",
-    "north_star_tolerance": "1e-3 rel: met by the fp32 instantiation of the same kernels (v_mfma_f32_32x32x2_f32; 1e-4 fwd / 5e-4 bwd "
-                            "at release dims, tests/test_release_dims_gpu.py), NOT by this bf16 line — a bf16 ulp is 4e-3 relative",
+    "release_width_vs_fp32_oracle": {
+        "where": "tests/test_release_width_gpu.py (Llama-3-8B-wide decoder, release-dimension towers, S = 2048, collator batch)",
+        "logits_max_rel": {"observed": 2.35e-2, "test_bound": 4e-2}, "logits_l2": {"observed": 1.7e-2, "test_bound": 3e-2},
+        "logits_slope_err": {"observed": 1.4e-4, "test_bound": 5e-3},
+        "worst_trainable_grad_tensor_max_rel": {"observed": 4.9e-2, "test_bound": 8e-2}},
+    "reference_own_bf16_vs_its_fp32": {
+        "where": "tests/golden/ref_bf16_twin_release_width.json (make_bf16_twin.py: the real cambrian_arch / vision_sampler / hook "
+                 "lines + installed-HF towers and decoder layers cast to bf16, same geometry and batch, build container)",
+        "logits_max_rel": 3.5e-2, "logits_l2": 2.6e-2, "logits_slope_err": 4.5e-4, "grad_tensor_median_max_rel": 3.3e-2,
+        "worst_grad_tensor_max_rel": 4.9e-1,
+        "assertion": "every HIP bf16 figure <= 1.5 x its reference-bf16 twin (test_release_width_gpu.py)"},
+    "hidden_256_model": {"logits_max_rel": "7.9e-3 .. 9.2e-3 (bound 2e-2)", "worst_grad": "1.5e-2 .. 1.9e-2 (bound 4e-2)",
+                         "where": "tests/test_model_gpu.py"},
+    "systematic_error_checks": "least-squares slope |s - 1| < 5e-3 (logits) / 2e-2 (gradients), relative L2 (tests/conftest.py::fit_err)",
+    "north_star_tolerance": "1e-3 rel holds for the fp32 path (1.2e-5 logits / 2.3e-5 gradients at release width), NOT for this bf16 "
+                            "line — a bf16 ulp is 4e-3 relative; the bf16 yardstick is the reference's own bf16 run above",
     "bit_exact": "window gather, masks, position ids, embedding splice, untouched hook rows (torch.equal in tests)",
 }
 

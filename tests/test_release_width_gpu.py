@@ -12,7 +12,14 @@ bf16 (the benched dtype) at this width rounds ~2.5x coarser than the hidden-256 
 rows, 2048-token softmaxes, 10 944-key SVA reductions: logits 4e-2 max-abs relative (observed 2.35e-2) with |slope - 1| <
 5e-3 (observed 1.4e-4: no systematic term) and L2 < 3e-2 (observed 1.7e-2); gradients 8e-2 max-abs (observed worst tensor
 4.9e-2), slope within 2e-2 and L2 within 6e-2 per tensor of >= 4096 elements (observed worst: the key-projection weights,
-whose gradients are small differences under the softmax's shift invariance: slope 1.1e-2, L2 3.7e-2).  DESIGN.md §3."""
+whose gradients are small differences under the softmax's shift invariance: slope 1.1e-2, L2 3.7e-2).  DESIGN.md §3.
+
+Round 4 (VERDICT r3 next #3a): the bf16 figures are ALSO held against what the REFERENCE'S OWN modules do in bf16 against
+themselves in fp32 at this geometry and on this batch — tests/golden/ref_bf16_twin_release_width.json, written in the build
+container by tests/golden/make_bf16_twin.py (real cambrian_arch.py / vision_sampler.py / hook lines, installed-HF towers and
+decoder layers, every module cast to bf16 as fsdp_config.json:6 runs them): logits 3.5e-2 max-abs / 2.6e-2 L2, median gradient
+tensor 3.3e-2, worst 4.9e-1 (LayerNorm biases of the 9216-token tower).  The HIP path must stay within 1.5x of each of those
+(it is 0.67x on the logits and 0.1x on the worst gradient: fp32 accumulators, statistics and master parameters)."""
 import json
 import os
 
@@ -129,7 +136,7 @@ def test_release_width_end_to_end(dev, monkeypatch, name, dt, tol_logits, tol_gr
     e, (sl, l2) = rel_err(lg, rl), fit_err(lg, rl)
     out.loss.backward()
     dloss = abs(out.loss.item() - ref_loss.item())
-    worst, bad, n_checked = ("", 0.0), [], 0
+    worst, bad, n_checked, errs = ("", 0.0), [], 0, []
     for n, q in model.named_parameters():
         if not q.requires_grad:
             continue
@@ -139,6 +146,7 @@ def test_release_width_end_to_end(dev, monkeypatch, name, dt, tol_logits, tol_gr
             continue
         err = rel_err(q.grad, g_ref)
         n_checked += 1
+        errs.append(err)
         if err > worst[1]:
             worst = (n, err)
         if g_ref.numel() >= 4096:
@@ -153,3 +161,20 @@ def test_release_width_end_to_end(dev, monkeypatch, name, dt, tol_logits, tol_gr
     assert n_checked > 150, n_checked
     assert not bad, f"{len(bad)} of {n_checked} gradient tensors off in slope / L2: {bad[:8]}"
     assert worst[1] < tol_grad, f"worst trainable-parameter gradient {worst}"
+    if name == "bf16":
+        # the reference's own bf16 execution as the yardstick (module docstring): every figure within 1.5x of its twin
+        twin = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                           "ref_bf16_twin_release_width.json")))
+        t_errs = sorted(v[0] for v in twin["grads"].values())
+        errs.sort()
+        q = lambda xs, f: xs[min(len(xs) - 1, int(f * len(xs)))]   # noqa: E731
+        ours = dict(logits_max_rel=e, logits_l2=l2, logits_slope_err=sl, grad_median=q(errs, 0.5), grad_p90=q(errs, 0.9),
+                    grad_max=errs[-1])
+        ref = dict(logits_max_rel=twin["logits_max_rel"], logits_l2=twin["logits_l2"], logits_slope_err=twin["logits_slope_err"],
+                   grad_median=q(t_errs, 0.5), grad_p90=q(t_errs, 0.9), grad_max=t_errs[-1])
+        _log(test="release_width_vs_reference_bf16_twin", hip=ours, reference_bf16=ref,
+             ratio={k: ours[k] / ref[k] for k in ours})
+        assert abs(len(errs) - len(t_errs)) <= 4, (len(errs), len(t_errs))    # the same trainable tensors on both sides
+        for k in ours:
+            assert ours[k] <= 1.5 * ref[k], (k, ours[k], ref[k])
+        assert dloss <= max(2.0 * twin["loss_abs_err"], 5e-4)
