@@ -24,7 +24,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
-KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN = 0, 1, 2   # enum cmb_knob_id
+KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS = 0, 1, 2, 3   # enum cmb_knob_id
 ABI_VERSION = 5   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
@@ -83,7 +83,7 @@ class SvaAbsDesc(C.Structure):
         ("q", C.c_void_p), ("ldq", C.c_int64),
         ("kv", C.c_void_p * SVA_MAX_TOWERS), ("ldkv", C.c_int64 * SVA_MAX_TOWERS),
         ("mask", C.c_void_p * SVA_MAX_TOWERS),
-        ("ra", C.c_int32),
+        ("ra", C.c_int32), ("dtype", C.c_int32),
         ("xhat", C.c_void_p), ("ldx", C.c_int64),
         ("mask_a", C.c_void_p),
         ("U", C.c_void_p), ("bk", C.c_void_p),

@@ -883,6 +883,24 @@ def k_gemm_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch
     return out
 
 
+def _per_head_wgrad(x: torch.Tensor, dy: torch.Tensor, heads: int, hd: int, Cin: int) -> torch.Tensor:
+    """dW[h*hd + j, :] = sum_q x[q, h*hd + j] dy[q, h, :]  ([heads*hd, Cin], fp32) — the weight gradient of the per-head
+    projections.  bf16: one batched split-K cmb_gemm_tn on the operands as they lie; other dtypes (the fp32 parity path):
+    transposed copies and one NT GEMM per head (cmb_gemm_tn is a bf16 kernel)."""
+    Bq = x.shape[0]
+    dw = torch.empty((heads * hd, Cin), dtype=torch.float32, device=x.device)
+    if x.dtype == torch.bfloat16:
+        k_gemm_tn(x, dy.view(Bq, heads * Cin), out=dw, M=hd, N=Cin, batch=heads, a_bs=hd, b_bs=Cin, c_bs=hd * Cin, ldc=Cin,
+                  split_k=_tn_splits(hd, Cin, Bq, heads))
+        return dw
+    m_pad = pad_to(Bq, _kstep(x.dtype))
+    x_t = k_transpose(x, m_pad)                                      # [heads*hd, m_pad]
+    dy_t = k_transpose(dy.view(Bq, heads * Cin), m_pad)              # [heads*Cin, m_pad]
+    for h in range(heads):
+        k_gemm(x_t[h * hd:(h + 1) * hd], dy_t[h * Cin:(h + 1) * Cin], out=dw[h * hd:(h + 1) * hd])
+    return dw
+
+
 class HeadExpandFn(torch.autograd.Function):
     """U[q, h, :] = x[q, h*hd:(h+1)*hd] @ W[h*hd:(h+1)*hd, :]   (x [Bq, H*hd], W [H*hd, Cin] -> U [Bq, H, Cin]): the K
     projection of the windowed tower applied to the QUERY (U = W_k,h^T q_h) and, with x = d(o), the V projection's backward
@@ -915,9 +933,7 @@ class HeadExpandFn(torch.autograd.Function):
             k_gemm_batched(dU, w_c, dx, batch=heads, M=Bq, N=hd, K=Cin, lda=heads * Cin, ldb=Cin, ldc=C, a_bs=Cin,
                            b_bs=hd * Cin, c_bs=hd)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((C, Cin), dtype=torch.float32, device=x.device)
-            k_gemm_tn(x, dU.view(Bq, heads * Cin), out=dw, M=hd, N=Cin, batch=heads, a_bs=hd, b_bs=Cin, c_bs=hd * Cin, ldc=Cin,
-                      split_k=_tn_splits(hd, Cin, Bq, heads))
+            dw = _per_head_wgrad(x, dU, heads, hd, Cin)
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         return dx, dw, None
@@ -957,9 +973,7 @@ class HeadContractFn(torch.autograd.Function):
             k_gemm_batched(dy, w_t, dxb, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=C, ldc=heads * Cin, a_bs=hd, b_bs=hd,
                            c_bs=Cin)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty((C, Cin), dtype=torch.float32, device=xb.device)
-            k_gemm_tn(dy, xb.view(Bq, heads * Cin), out=dw, M=hd, N=Cin, batch=heads, a_bs=hd, b_bs=Cin, c_bs=hd * Cin, ldc=Cin,
-                      split_k=_tn_splits(hd, Cin, Bq, heads))
+            dw = _per_head_wgrad(dy, xb, heads, hd, Cin)
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         return dxb, dw, None
@@ -967,6 +981,7 @@ class HeadContractFn(torch.autograd.Function):
 
 def _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, U, bk, bv, B, qside, window_major):
     d.B, d.qside, d.heads, d.hd = B, qside, 16, 64
+    d.dtype = L.dtype_code(q.dtype)
     d.ntowers, d.window_major, d.ra = len(kvs), 1 if window_major else 0, ra
     d.q, d.ldq = q.data_ptr(), q.stride(0)
     for i, kv in enumerate(kvs):
@@ -987,8 +1002,10 @@ class SvaAbsorbedFn(torch.autograd.Function):
     def forward(ctx, q, U, bk, bv, xhat, B: int, qside: int, ra: int, masks, mask_a, window_major: bool, *kvs):
         L.require_gpu(q, U, bk, bv, xhat, *kvs)
         Bq = B * qside * qside
-        if q.dtype != torch.bfloat16 or tuple(q.shape) != (Bq, 1024) or tuple(U.shape) != (Bq, 16, 1024):
-            raise L.CambrianAmdError("absorbed SVA attention: bf16, 16 heads x 64, 1024-wide features")
+        if q.dtype not in (torch.bfloat16, torch.float32) or tuple(q.shape) != (Bq, 1024) or tuple(U.shape) != (Bq, 16, 1024):
+            raise L.CambrianAmdError("absorbed SVA attention: bf16 / fp32, 16 heads x 64, 1024-wide features")
+        if any(t.dtype != q.dtype for t in (U, xhat, *kvs)):
+            raise L.CambrianAmdError("absorbed SVA attention: q, U, xhat and the K|V rows must share one dtype")
         if xhat.shape[0] != B * (qside * ra) ** 2 or xhat.shape[1] != 1024 or xhat.stride(1) != 1:
             raise L.CambrianAmdError("absorbed SVA attention: xhat must be [B*(qside*ra)^2, 1024]")
         # dense rows: the backward kernel writes dK|dV with the K|V row stride (cmb_sva_abs_desc has no separate lddkv) into

@@ -73,8 +73,10 @@ int cmb_abi_version(void);
  *                       rows / 16 workgroups up to 8192; > 1 = the same with that workgroup cap
  *   CMB_KNOB_DWCONV     cmb_dwconv7x7_nhwc (C % 64 == 0): 0 = LDS-tiled kernel (rounds 1-3); 1 = column-walking kernel with
  *                       register-resident taps, 64 rows per chunk for maps of >= 128 rows, else 32; > 1 = that many rows per chunk
- *   CMB_KNOB_VIT_ATTN   cmb_vit_attn_fwd (bf16): 0 = two barriers per key tile (round 3); 1 = two LDS tile buffers, one barrier */
-enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_COUNT = 8 };
+ *   CMB_KNOB_VIT_ATTN   cmb_vit_attn_fwd (bf16): 0 = two barriers per key tile (round 3); 1 = two LDS tile buffers, one barrier
+ *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
+ *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other) */
+enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_COUNT = 8 };
 #define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 0, 0, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
@@ -260,7 +262,8 @@ int cmb_sva_attn_bwd(const cmb_sva_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * SVA cross-attention core with ONE windowed tower's K / V projections absorbed into the query side
- * (same reference lines as above: vision_sampler.py:187-230; bf16, heads = 16, hd = 64, feature width 1024).
+ * (same reference lines as above: vision_sampler.py:187-230; heads = 16, hd = 64, feature width 1024; bf16 on the MFMA, or
+ * fp32 through an exact instantiation of the same algorithm — `dtype`).
  * Every token of an s x s-window tower is seen by exactly one query, so instead of projecting K and V per token
  * (kv_i above) the caller supplies, for that tower,
  *   xhat : [B * (qside*ra)^2, 1024]  the LayerNorm-normalised tokens (affines folded into W_k, W_v, b_k, b_v)
@@ -285,6 +288,8 @@ typedef struct cmb_sva_abs_desc {
   const void* kv[CMB_SVA_MAX_TOWERS]; int64_t ldkv[CMB_SVA_MAX_TOWERS];
   const uint8_t* mask[CMB_SVA_MAX_TOWERS];
   int32_t ra;            /* window side of the absorbed tower, ra*ra <= 16 */
+  int32_t dtype;         /* CMB_BF16 (= 0: the MFMA kernels) | CMB_F32 (the exact instantiation of the same algorithm: plain fp32
+                            arithmetic, test speed): element type of q, kv, xhat, U, out, xbar and of every gradient */
   const void* xhat; int64_t ldx;
   const uint8_t* mask_a; /* uint8 [Bq, ra*ra] or NULL */
   const void* U;
