@@ -75,7 +75,8 @@ int cmb_abi_version(void);
  *                       register-resident taps, 64 rows per chunk for maps of >= 128 rows, else 32; > 1 = that many rows per chunk
  *   CMB_KNOB_VIT_ATTN   cmb_vit_attn_fwd (bf16): 0 = two barriers per key tile (round 3); 1 = two LDS tile buffers, one barrier
  *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
- *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other) */
+ *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
+ */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_COUNT = 8 };
 #define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 0, 0, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */

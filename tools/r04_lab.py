@@ -163,3 +163,30 @@ if "g128" in only:
         us = timeit(lambda: ops.k_gemm_tn(g, x, split_k=sk))
         emit(kernel="gemm_tn_kernel", shape=f"{name} {rows} -> {n_out}x{k_in} split {sk}", us=round(us, 1),
              tflops=round(2.0 * rows * n_out * k_in / us / 1e6, 1))
+
+if "epi" in only:
+    # gemm_nt_p5_kernel per epilogue form (bias / LayerScale / residual) on the path's shapes
+    shapes = [("ConvNeXt s3 fc2 +b+ls+res", B * 4096, 1536, 6144, "bcr"), ("ConvNeXt s2 fc2 +b+ls+res", B * 16384, 768, 3072, "bcr"),
+              ("DINOv2 fc1 +b", B * 730, 8192, 1536, "b"), ("DINOv2 qkv +b", B * 730, 4608, 1536, "b"),
+              ("DINOv2 fc2 +b+ls+res", B * 730, 1536, 4096, "bcr"), ("CLIP fc2 +b+res", B * 577, 1024, 4096, "br"),
+              ("ConvNeXt s1 fc1 +b gelu", B * 65536, 1536, 384, "bg"), ("K|V +b", B * 576, 2048, 1024, "b"),
+              ("plain", B * 4096, 6144, 1536, "")]
+    for name, M, N, K, mode in shapes:
+        a, w = rn(M, K), rn(N, K, scale=K ** -0.5)
+        kw = {}
+        if "b" in mode:
+            kw["bias"] = rn(N, dtype=f32)
+        if "c" in mode:
+            kw["colscale"] = rn(N, dtype=f32)
+        if "r" in mode:
+            kw["residual"] = rn(M, N)
+        if "g" in mode:
+            kw["act"] = L.ACT_GELU_ERF
+        out = torch.empty(M, N, device=dev, dtype=bf)
+        ops.k_gemm(a, w, out=out, tile=2590, **kw)
+        us = timeit(lambda: ops.k_gemm(a, w, out=out, tile=2590, **kw), iters=10)
+        emit(kernel="gemm_p5 epilogue", shape=f"{name} {M}x{N}x{K}", us=round(us, 1), tflops=round(2.0 * M * N * K / us / 1e6, 1))
+        o8 = ops.k_gemm(a[:4096], w, tile=2560, **{k: (v[:4096] if k == "residual" else v) for k, v in kw.items()})
+        emit(kernel="gemm_p5 epilogue", shape=name, check="p5 == 8-wave kernel, bit for bit (first 4096 rows)",
+             equal=bool(torch.equal(o8, out[:4096])))
+        del a, w, out, kw
