@@ -340,6 +340,152 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm backward of SEVERAL non-affine LayerNorms of the SAME input (round 4): the 13 SVA layers normalise one aux
+// feature tensor each with its own position table, xh_l = normalise(x + pos_l[window position]) (vision_sampler.py:304-309,
+// cambrian_arch.py:271-287), and d(x) = sum_l J_l^T d(xh_l).  Layer by layer (layernorm_bwd_kernel with the fp32
+// accumulator) that is 13 x (dy 2 + x 2 + accumulator 4 + 4) = 156 bytes per element of the 9216-token tower — 7.7 ms per
+// 24-image step at 4.6 TB/s.  Here the layers' d(xh_l) are kept until the last of them has run (5.9 GB at 24 images), and
+// ONE pass reads x once, the L gradients once each and writes d(x) once: 2 + 2 L + 4 bytes per element (32 at L = 13).
+// Rows are enumerated window-major as above (blockIdx.y = window position), so a lane's d(pos_l) partial sums are registers
+// — LC sets per launch (a first version kept L x D sums in LDS and added to them with ds_add_f32: 208 LDS atomics per row
+// made the pass 2x SLOWER than layer by layer); a launch therefore covers 4 layers (13 layers = 4 + 4 + 4 + 1: 62 bytes
+// per element; 7 per launch needs 320 registers = one wave per SIMD and measured SLOWER: 6.6 ms against 4.7 ms, and 6.9 ms
+// layer by layer, 24 images, profiles/r04_lab.md), every layer's gradient row requested before the first is reduced.
+// ------------------------------------------------------------------------------------------------
+struct LnMultiParams {
+  int layers;
+  const void* dy[CMB_LN_MULTI_MAX];
+  const float* add[CMB_LN_MULTI_MAX];
+  const float* mean[CMB_LN_MULTI_MAX];
+  const float* rstd[CMB_LN_MULTI_MAX];
+  float* dadd[CMB_LN_MULTI_MAX];
+};
+
+template <typename T, int NCH, bool ACCUM, int LC>
+__global__ void __launch_bounds__(256) layernorm_bwd_multi_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int D,
+                                                                  int side, int grid_r, const LnMultiParams mp,
+                                                                  float* __restrict__ dx, int64_t lddx) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* sred = reinterpret_cast<float*>(dyn_smem);  // [4 waves][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = D >> 3;
+  const int pos = blockIdx.y;
+  const int py = pos / grid_r, px = pos - py * grid_r;
+  const int qside = side / grid_r;
+  const int64_t nwin = rows / ((int64_t)grid_r * grid_r);
+  // d(pos_l) partial sums of this lane's columns, one set per layer of the launch (LC <= 7 layers: 7 x NCH x 8 registers)
+  float pa[LC][NCH][8];
+#pragma unroll
+  for (int l = 0; l < LC; ++l)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pa[l][c][e] = 0.f;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t w = wave_global; w < nwin; w += nwaves) {
+    int64_t row;
+    if (grid_r == 1) {
+      row = w;
+    } else {
+      const int64_t b = w / ((int64_t)qside * qside);
+      const int t = (int)(w - b * (int64_t)qside * qside);
+      const int qy = t / qside, qx = t - qy * qside;
+      row = b * (int64_t)side * side + (int64_t)(qy * grid_r + py) * side + (qx * grid_r + px);
+    }
+    float xv[NCH][8], acc[NCH][8];
+    // every layer's gradient row is requested up front: LC + 1 round trips in flight per wave instead of one after another
+    Raw8<T> raw[LC][NCH];
+#pragma unroll
+    for (int l = 0; l < LC; ++l) {
+      if (l < mp.layers) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int vi = lane + c * 64;
+          if (vi < nvec) raw[l][c].load(reinterpret_cast<const T*>(mp.dy[l]) + row * (int64_t)D + vi * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        Vec8<T>::load(x + row * ldx + vi * 8, xv[c]);
+        if (ACCUM) load8f(dx + row * lddx + vi * 8, acc[c]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < LC; ++l) {
+      if (l < mp.layers) {   // wave-uniform
+        const float mean = mp.mean[l][row], rstd = mp.rstd[l][row];
+        const float* ar = mp.add[l] ? mp.add[l] + (int64_t)pos * D : nullptr;
+        float xh[NCH][8], g[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int vi = lane + c * 64;
+          if (vi < nvec) {
+            raw[l][c].get(g[c]);
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ar) load8f(ar + vi * 8, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              xh[c][e] = (xv[c][e] + a[e] - mean) * rstd;
+              s1 += g[c][e];
+              s2 += g[c][e] * xh[c][e];
+            }
+          }
+        }
+        const float c1 = wave_sum(s1) / (float)D;
+        const float c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int vi = lane + c * 64;
+          if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float o = (g[c][e] - c1 - xh[c][e] * c2) * rstd;
+              acc[c][e] += o;
+              pa[l][c][e] += o;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) Vec8<float>::store(dx + row * lddx + vi * 8, acc[c]);
+    }
+  }
+  // block-level combine of each layer's partial sums through sred[4][D], then one atomicAdd per column per workgroup
+#pragma unroll
+  for (int l = 0; l < LC; ++l) {
+    if (l < mp.layers && mp.add[l] && mp.dadd[l]) {   // block-uniform
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int vi = lane + c * 64;
+        if (vi < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sred[wave * D + vi * 8 + e] = pa[l][c][e];
+        }
+      }
+      __syncthreads();
+      float* out = mp.dadd[l] + (int64_t)pos * D;
+      for (int col = threadIdx.x; col < D; col += 256) {
+        const float t = sred[col] + sred[D + col] + sred[2 * D + col] + sred[3 * D + col];
+        if (t != 0.f) atomicAdd(out + col, t);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // RMSNorm
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NCH>
@@ -734,6 +880,60 @@ extern "C" int cmb_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const 
                                        lddx, dgamma, dbeta, dadd, s);
   }
   return CMB_ERR_BAD_ARG;
+}
+
+extern "C" int cmb_layernorm_bwd_multi(const cmb_ln_multi_desc* d, void* stream) {
+  if (!d || !d->x || !d->dx || d->rows < 0 || d->D <= 0 || (d->D & 7) || d->layers <= 0 || d->layers > CMB_LN_MULTI_MAX)
+    return CMB_ERR_BAD_ARG;
+  if (d->dtype != CMB_BF16 && d->dtype != CMB_F32) return CMB_ERR_BAD_ARG;
+  int side = d->side, grid_r = d->grid_r;
+  bool any_add = false;
+  for (int l = 0; l < d->layers; ++l) {
+    if (!d->dy[l] || !d->mean[l] || !d->rstd[l]) return CMB_ERR_BAD_ARG;
+    any_add = any_add || d->add[l];
+  }
+  if (any_add && (side <= 0 || grid_r <= 0 || side % grid_r)) return CMB_ERR_BAD_ARG;
+  if (!any_add) { side = 1; grid_r = 1; }
+  if (d->rows == 0) return CMB_OK;
+  if (any_add && d->rows % ((int64_t)side * side)) return CMB_ERR_SHAPE;
+  const int nch = nch_for(d->D);
+  if (nch != 2) return CMB_ERR_SHAPE;   // D <= 1024 (the SVA feature width): 7 layers x 16 partial sums per lane
+  const size_t smem = (size_t)4 * d->D * sizeof(float);
+  const int npos = grid_r * grid_r;
+  const int64_t nwin = d->rows / npos;
+  int64_t blocks = (nwin + 31) / 32;   // ~8 rows per wave: amortises the end-of-workgroup combine
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int kChunk = cmb_knob(CMB_KNOB_LN_MULTI_CHUNK) == 4 ? 4 : 7;   // layers per launch (4: two waves per SIMD)
+  for (int l0 = 0; l0 < d->layers; l0 += kChunk) {
+    LnMultiParams mp;
+    mp.layers = d->layers - l0 < kChunk ? d->layers - l0 : kChunk;
+    for (int l = 0; l < CMB_LN_MULTI_MAX; ++l) {
+      const bool on = l < mp.layers;
+      mp.dy[l] = on ? d->dy[l0 + l] : nullptr;
+      mp.add[l] = on ? d->add[l0 + l] : nullptr;
+      mp.mean[l] = on ? d->mean[l0 + l] : nullptr;
+      mp.rstd[l] = on ? d->rstd[l0 + l] : nullptr;
+      mp.dadd[l] = on ? d->dadd[l0 + l] : nullptr;
+    }
+    const bool acc = d->accumulate || l0 > 0;
+#define LN_MULTI_LAUNCH(T_, ACC_, LC_)                                                                                  \
+  hipLaunchKernelGGL((layernorm_bwd_multi_kernel<T_, 2, ACC_, LC_>), dim3((unsigned)blocks, npos), dim3(256), smem, s,  \
+                     (const T_*)d->x, d->ldx, d->rows, (int)d->D, side, grid_r, mp, d->dx, d->lddx)
+#define LN_MULTI_T(T_)                                                                      \
+  do {                                                                                      \
+    if (mp.layers > 4) { if (acc) LN_MULTI_LAUNCH(T_, true, 7); else LN_MULTI_LAUNCH(T_, false, 7); } \
+    else if (mp.layers > 2) { if (acc) LN_MULTI_LAUNCH(T_, true, 4); else LN_MULTI_LAUNCH(T_, false, 4); } \
+    else { if (acc) LN_MULTI_LAUNCH(T_, true, 2); else LN_MULTI_LAUNCH(T_, false, 2); }      \
+  } while (0)
+    if (d->dtype == CMB_BF16) LN_MULTI_T(bf16_t);
+    else LN_MULTI_T(float);
+#undef LN_MULTI_T
+#undef LN_MULTI_LAUNCH
+    CMB_CHECK_LAUNCH();
+  }
+  return CMB_OK;
 }
 
 extern "C" int cmb_rmsnorm_fwd(int dtype, const void* x, int64_t rows, int64_t D, const float* w, float eps,

@@ -24,7 +24,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
-KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS = 0, 1, 2, 3   # enum cmb_knob_id
+KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS, KNOB_LN_MULTI_CHUNK = 0, 1, 2, 3, 4   # enum cmb_knob_id
 ABI_VERSION = 5   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
@@ -98,6 +98,23 @@ class SvaAbsDesc(C.Structure):
     ]
 
 
+LN_MULTI_MAX = 16
+
+
+class LnMultiDesc(C.Structure):
+    """cmb_ln_multi_desc (include/cambrian_amd.h): backward of several LayerNorms of one input in one pass."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("layers", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("rows", C.c_int64), ("D", C.c_int64),
+        ("side", C.c_int32), ("grid_r", C.c_int32),
+        ("dy", C.c_void_p * LN_MULTI_MAX), ("add", C.c_void_p * LN_MULTI_MAX), ("mean", C.c_void_p * LN_MULTI_MAX),
+        ("rstd", C.c_void_p * LN_MULTI_MAX), ("dadd", C.c_void_p * LN_MULTI_MAX),
+        ("dx", C.c_void_p), ("lddx", C.c_int64),
+        ("accumulate", C.c_int32),
+    ]
+
+
 class ImageJob(C.Structure):
     """cmb_image_job (include/cambrian_amd.h): one (sample, tower) unit of the image pre-processing launch."""
     _fields_ = [
@@ -127,6 +144,7 @@ SIGNATURES = {
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_cast": (C.c_int, [C.c_int, _p, C.c_int, _p, _i64, _p]),
+    "cmb_layernorm_bwd_multi": (C.c_int, [C.POINTER(LnMultiDesc), _p]),
     "cmb_layernorm_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _p, _i64, _p, _p, _p]),
     "cmb_layernorm_bwd": (C.c_int, [C.c_int, _p, _i64, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _i64,
                                     _i32, _p, _p, _p, _p]),

@@ -299,12 +299,17 @@ class CambrianMetaForCausalLM(ABC):
         if cfg.mm_projector_type == "sva":
             vh = cfg.vision_hidden_size
             feats, holders = [], []
+            # every sampler that will normalise these features (connector groups, then the in-LLM layers): their position
+            # tables are announced to shared_grad so that the 13 LayerNorm backwards of a tower run as one pass at the end
+            samplers = [getattr(model, f"vision_sampler_{g}") for g in range(len(cfg.query_num_list))]
+            samplers += list(getattr(model, "vision_sampler_layers", []) or [])
             for aux_i in range(len(towers)):                                         # :372-379
                 f = feats_raw[aux_i]
                 f = getattr(model, f"mm_projector_aux_{aux_i}")(f.to(dtype)).to(dtype)
                 holders.append(ops.GradAccumulator())
                 f2 = f.reshape(-1, vh)
-                feats.append(ops.shared_grad(f2, holders[-1]) if f2.requires_grad else f2)
+                tables = [t for sm in samplers for t in sm.pos_tables(aux_i)]
+                feats.append(ops.shared_grad(f2, holders[-1], tables) if f2.requires_grad else f2)
             T0 = feats_raw[0].shape[1]
             ctx_b = ops.token_mean(feats[0].view(bs, T0, vh), holders[0] if feats[0].requires_grad else None)  # [B, C] (:377)
             masks_u8 = self._masks_u8(image_aux_attention_masks_list, bs, side, feats)

@@ -97,6 +97,11 @@ class VisionCrossAttentionLayer(nn.Module):
             if kv_size > 1:
                 setattr(self, f"pos_embed_{i}", nn.Parameter(torch.randn(kv_size ** 2, hidden_dim)))
 
+    def pos_tables(self, i: int):
+        """The position table this layer adds to tower i's tokens ([] for a one-key tower): announced to ops.shared_grad so
+        that the layers' LayerNorm backwards can run as one deferred pass (ops.GradAccumulator)."""
+        return [getattr(self, f"pos_embed_{i}")] if self.kv_size_list[i] > 1 else []
+
     # ------------------------------------------------------------------------------------------
     def _run(self, q2: torch.Tensor, ctx2: torch.Tensor, ctx_rep: int, feats: Sequence[torch.Tensor],
              masks_u8: Sequence[Optional[torch.Tensor]], holders: Sequence[ops.GradAccumulator], B: int, qside: int,
@@ -179,7 +184,7 @@ class VisionCrossAttentionLayer(nn.Module):
             f = lat.reshape(-1, lat.shape[-1])
             if f.dtype != queries.dtype:
                 f = f.to(queries.dtype)
-            feats.append(ops.shared_grad(f, holders[i]) if _holders is None and f.requires_grad else f)
+            feats.append(ops.shared_grad(f, holders[i], self.pos_tables(i)) if _holders is None and f.requires_grad else f)
         out = self._run(queries.reshape(Bq, -1), context_feature.reshape(Bq, -1), 0, feats, masks_u8, holders,
                         B=Bq, qside=1, window_major=True)
         return out.view(Bq, 1, -1)
@@ -208,10 +213,14 @@ class VisionTokenSampler(nn.Module):
         shared = []
         for i, lat in enumerate(latents):
             f = lat if lat.dtype == queries.dtype else lat.to(queries.dtype)
-            shared.append(ops.shared_grad(f, holders[i]) if f.requires_grad else f)
+            shared.append(ops.shared_grad(f, holders[i], self.pos_tables(i)) if f.requires_grad else f)
         for layer in self.layers:
             queries = layer(queries, context_feature, *shared, *masks, _holders=holders)
         return queries
+
+    def pos_tables(self, i: int):
+        """Position tables of all this sampler's layers for tower i (VisionCrossAttentionLayer.pos_tables)."""
+        return [t for layer in self.layers for t in layer.pos_tables(i)]
 
     def forward_fused(self, q2: torch.Tensor, ctx_b: torch.Tensor, feats: Sequence[torch.Tensor],
                       masks_u8: Sequence[Optional[torch.Tensor]], holders: Sequence[ops.GradAccumulator], B: int,

@@ -704,13 +704,26 @@ def layernorm(x, gamma, beta, eps: float = 1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+DEFER_LN_BWD = os.environ.get("CAMBRIAN_AMD_DEFER_LN_BWD", "1") != "0"   # (A/B runs: 0 = one LayerNorm backward per SVA layer)
+
+
 class GradAccumulator:
     """fp32 side buffer that the 13 SVA layers' LayerNorm backwards accumulate into (all layers read the
-    same aux feature tensor; SURVEY.md §7 "hard parts")."""
+    same aux feature tensor; SURVEY.md §7 "hard parts").
+
+    Round 4: the layers' LayerNorm backwards can be DEFERRED — each SvaNormFn.backward parks (d xh_l, mean_l, rstd_l, pos_l)
+    here instead of running, and SharedGradFn.backward (which autograd runs after all of them) does them in ONE pass over x
+    (cmb_layernorm_bwd_multi: 32 instead of 156 bytes per element for 13 layers).  The gradients of the position tables come
+    out of that pass, so they are returned by SharedGradFn.backward: the tables are formally inputs of shared_grad()
+    (``pos_params``) and SvaNormFn returns no gradient for them.  A layer whose table was not announced runs the immediate
+    path."""
 
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
         self.shape = None
+        self.defer = False
+        self.pos_index = {}     # data_ptr of an announced position table -> its slot in SharedGradFn's inputs
+        self.deferred = []      # (dn, x, mean, rstd, add fp32 | None, side, grid_r, slot | -1)
 
     def get(self, rows: int, D: int, device) -> torch.Tensor:
         if self.buf is None:
@@ -718,32 +731,74 @@ class GradAccumulator:
         return self.buf
 
 
+def k_layernorm_bwd_multi(x: torch.Tensor, items, side: int, grid_r: int, dx: torch.Tensor, accumulate: bool, dadd_out):
+    """cmb_layernorm_bwd_multi over ``items`` = [(dn, mean, rstd, add | None, slot)]: dx (fp32 [rows, D]) (+)= the summed
+    LayerNorm backwards; ``dadd_out[slot]`` (fp32, zero-filled, same shape as the table) receives each layer's table gradient."""
+    L.require_gpu(x, dx)
+    rows, D = x.shape
+    for lo in range(0, len(items), L.LN_MULTI_MAX):
+        chunk = items[lo:lo + L.LN_MULTI_MAX]
+        d = L.LnMultiDesc()
+        d.dtype, d.layers = L.dtype_code(x.dtype), len(chunk)
+        d.x, d.ldx, d.rows, d.D, d.side, d.grid_r = x.data_ptr(), x.stride(0), rows, D, side, grid_r
+        for i, (dn, mean, rstd, add, slot) in enumerate(chunk):
+            if dn.dtype != x.dtype or not dn.is_contiguous() or tuple(dn.shape) != (rows, D):
+                raise L.CambrianAmdError("layernorm_bwd_multi: every gradient must be a dense [rows, D] tensor of x's dtype")
+            d.dy[i], d.mean[i], d.rstd[i] = dn.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            d.add[i] = None if add is None else add.data_ptr()
+            d.dadd[i] = None if (add is None or slot < 0 or dadd_out[slot] is None) else dadd_out[slot].data_ptr()
+        d.dx, d.lddx, d.accumulate = dx.data_ptr(), dx.stride(0), 1 if (accumulate or lo > 0) else 0
+        L.check(L.load().cmb_layernorm_bwd_multi(C.byref(d), L.stream_ptr(x.device)), "cmb_layernorm_bwd_multi")
+
+
 class SharedGradFn(torch.autograd.Function):
     """Identity whose backward hands out the accumulator filled by the consumers (which themselves return
     no gradient for this tensor).  Autograd runs this node only after every consumer node has run, because
-    dependencies are counted on graph edges, not on defined gradients."""
+    dependencies are counted on graph edges, not on defined gradients.  ``pos_params``: the position tables of the SVA
+    layers that will normalise this tensor (GradAccumulator: deferred LayerNorm backwards)."""
 
     @staticmethod
-    def forward(ctx, x, holder: GradAccumulator):
+    def forward(ctx, x, holder: GradAccumulator, *pos_params):
         ctx.holder = holder
         holder.shape = x.shape
+        holder.defer = DEFER_LN_BWD
+        holder.pos_index = {p.data_ptr(): i for i, p in enumerate(pos_params)}
+        holder.deferred = []
         ctx.x_dtype = x.dtype
+        ctx.pos_meta = [(tuple(p.shape), p.dtype) for p in pos_params]
         ctx.set_materialize_grads(False)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        buf = ctx.holder.buf
-        ctx.holder.buf = None
+        h = ctx.holder
+        buf, items = h.buf, h.deferred
+        h.buf, h.deferred = None, []
+        dpos = [None] * len(ctx.pos_meta)
+        if items:
+            x = items[0][1]
+            groups = {}
+            for dn, _x, mean, rstd, add, side, grid_r, slot in items:
+                if slot >= 0 and dpos[slot] is None and ctx.needs_input_grad[2 + slot]:
+                    dpos[slot] = torch.zeros(ctx.pos_meta[slot][0], dtype=torch.float32, device=x.device)
+                groups.setdefault((side, grid_r) if add is not None else (1, 1), []).append((dn, mean, rstd, add, slot))
+            have = buf is not None
+            if buf is None:
+                buf = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+            for (side, grid_r), its in groups.items():
+                k_layernorm_bwd_multi(x, its, side, grid_r, buf, have, dpos)
+                have = True
+            dpos = [None if t is None else (t if ctx.pos_meta[i][1] == torch.float32 else t.to(ctx.pos_meta[i][1]))
+                    for i, t in enumerate(dpos)]
         if buf is None:
-            return g, None
+            return (g, None, *dpos)
         if g is not None:
             buf = buf + g.to(torch.float32).reshape(buf.shape)
-        return k_cast(buf, ctx.x_dtype).view(ctx.holder.shape), None
+        return (k_cast(buf, ctx.x_dtype).view(h.shape), None, *dpos)
 
 
-def shared_grad(x: torch.Tensor, holder: GradAccumulator) -> torch.Tensor:
-    return SharedGradFn.apply(x, holder)
+def shared_grad(x: torch.Tensor, holder: GradAccumulator, pos_params=()) -> torch.Tensor:
+    return SharedGradFn.apply(x, holder, *pos_params)
 
 
 class SvaNormFn(torch.autograd.Function):
@@ -756,6 +811,7 @@ class SvaNormFn(torch.autograd.Function):
         add = None if pos is None else k_cast(pos, torch.float32)
         n, mean, rstd = k_layernorm_fwd(x, None, None, eps, add=add, side=side, grid_r=grid_r)
         ctx.holder, ctx.side, ctx.grid_r = holder, side, grid_r
+        ctx.pos_key = None if pos is None else pos.data_ptr()
         ctx.pos_dtype = None if pos is None else pos.dtype
         ctx.has_pos = pos is not None
         if pos is None:
@@ -772,9 +828,16 @@ class SvaNormFn(torch.autograd.Function):
             (x, mean, rstd), add = ctx.saved_tensors, None
         dn = _as_dtype_contig(dn, x.dtype)
         need_x, need_pos = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        h = ctx.holder
+        if need_x and h.defer and x.is_contiguous() and x.shape[1] <= 1024:
+            slot = -1 if add is None else h.pos_index.get(ctx.pos_key, -2)
+            if slot != -2 and not (h.deferred and h.deferred[0][1].data_ptr() != x.data_ptr()):
+                # parked: SharedGradFn.backward runs every layer's LayerNorm backward in one pass and returns d(pos)
+                h.deferred.append((dn, x, mean, rstd, add, ctx.side, ctx.grid_r, slot))
+                return None, None, None, None, None, None
         dpos = None
         if need_x:
-            acc = ctx.holder.get(x.shape[0], x.shape[1], x.device)
+            acc = h.get(x.shape[0], x.shape[1], x.device)
             _, _, _, dpos = k_layernorm_bwd(dn, x, mean, rstd, add=add, side=ctx.side, grid_r=ctx.grid_r, dx_acc=acc,
                                             want_dadd=need_pos)
         elif need_pos and add is not None:

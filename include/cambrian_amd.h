@@ -76,9 +76,10 @@ int cmb_abi_version(void);
  *   CMB_KNOB_VIT_ATTN   cmb_vit_attn_fwd (bf16): 0 = two barriers per key tile (round 3); 1 = two LDS tile buffers, one barrier
  *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
  *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
- */
-enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 0, 0, 0, 0
+ *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 7 (one wave per SIMD) or 4 (two) */
+enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
+                   CMB_KNOB_COUNT = 8 };
+#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 0, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 
@@ -202,6 +203,33 @@ int cmb_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const void* x, in
                       const float* gamma, const float* mean, const float* rstd,
                       void* dx, int64_t lddx, int32_t dx_accumulate,
                       float* dgamma, float* dbeta, float* dadd, void* stream);
+
+/* Backward of SEVERAL non-affine LayerNorms of one input in one pass (the 13 SVA layers each normalise the same aux feature
+ * tensor with their own position table: vision_sampler.py:304-309 reached 13 times per step, cambrian_llama.py:168-207):
+ *   dx[r,:] (+)= sum_l  rstd_l[r] * ( dy_l[r,:] - mean(dy_l[r,:]) - xh_l[r,:] * mean(dy_l[r,:] * xh_l[r,:]) ),
+ *   xh_l[r,:] = (x[r,:] + add_l[pos(r),:] - mean_l[r]) * rstd_l[r],      dadd_l[pos,:] += the layer's term summed over rows
+ * with mean_l / rstd_l as cmb_layernorm_fwd returned them (add = add_l, no gamma / beta) and pos(r) the window position
+ * of row r on a side x side grid in grid_r x grid_r windows (as cmb_layernorm_fwd).  x is read once, every dy_l once
+ * (dense rows: leading dimension D), dx (fp32, leading dimension lddx) is written once (`accumulate` != 0: added to).
+ * add[l] may be NULL (no table for that layer; then dadd[l] is ignored); dadd[l] may be NULL (gradient not wanted);
+ * caller zero-fills dadd.  layers <= CMB_LN_MULTI_MAX (run as launches of up to 7 layers: x is read once per launch),
+ * D <= 1024. */
+#define CMB_LN_MULTI_MAX 16
+typedef struct cmb_ln_multi_desc {
+  int32_t dtype;          /* CMB_BF16 | CMB_F32: element type of x and dy_l */
+  int32_t layers;
+  const void* x;  int64_t ldx;
+  int64_t rows, D;
+  int32_t side, grid_r;
+  const void* dy[CMB_LN_MULTI_MAX];
+  const float* add[CMB_LN_MULTI_MAX];
+  const float* mean[CMB_LN_MULTI_MAX];
+  const float* rstd[CMB_LN_MULTI_MAX];
+  float* dadd[CMB_LN_MULTI_MAX];
+  float* dx;      int64_t lddx;
+  int32_t accumulate;
+} cmb_ln_multi_desc;
+int cmb_layernorm_bwd_multi(const cmb_ln_multi_desc* d, void* stream);
 
 /* RMSNorm: y = (x * rsqrt(mean(x^2)+eps)) * w, fp32 math, weight multiplied BEFORE the down-cast
  * (the reference's patched LlamaRMSNorm: train_fsdp.py:1429-1438; phi3/modeling_phi3.py:83-97). */

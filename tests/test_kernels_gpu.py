@@ -603,3 +603,51 @@ def test_vit_attn_variants(dev, N, heads, hd):
     assert torch.equal(outs[0], outs[1])
     want = vit_ops.k_vit_attn(qkv.float(), B, N, heads, hd, hd ** -0.5)
     assert rel_err(outs[1], want) < 1e-2
+
+
+@pytest.mark.parametrize("name,dt", DTYPES)
+@pytest.mark.parametrize("L_,D,side,r,with_acc", [(13, 1024, 8, 4, True), (3, 1024, 6, 2, False), (17, 1024, 4, 1, False),
+                                                    (5, 512, 8, 4, True), (2, 384, 4, 2, False)])
+def test_layernorm_bwd_multi_equals_layer_by_layer(dev, name, dt, L_, D, side, r, with_acc):
+    """cmb_layernorm_bwd_multi (one pass over x for all layers: the SVA layers' deferred LayerNorm backwards) against
+    cmb_layernorm_bwd run layer by layer into the fp32 accumulator, and against autograd of F.layer_norm: d(x) and every
+    position table's gradient; grid_r = 1 layers carry no table; more layers than one launch holds (17 > 16)."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(L_ * D + side)
+    B = 3
+    rows = B * side * side
+    x = _rand(g, rows, D).to(dt)
+    adds = [(_rand(g, r * r, D) if r > 1 else None) for _ in range(L_)]
+    dys = [_rand(g, rows, D).to(dt) for _ in range(L_)]
+    acc0 = _rand(g, rows, D) if with_acc else None
+    # autograd reference
+    xr = x.float().clone().requires_grad_()
+    ars = [None if a is None else a.clone().requires_grad_() for a in adds]
+    wp = _window_pos(rows, side, r)
+    tot = 0.0
+    for a, dy in zip(ars, dys):
+        xin = xr if a is None else xr + a[wp]
+        tot = tot + (F.layer_norm(xin, (D,), None, None, 1e-5) * dy.float()).sum()
+    tot.backward()
+    ref_dx = xr.grad + (acc0 if with_acc else 0.0)
+    xd = x.to(dev)
+    items, seq_acc = [], (acc0.clone().to(dev) if with_acc else torch.zeros(rows, D, device=dev))
+    dadd = []
+    for a, dy in zip(adds, dys):
+        ad = None if a is None else a.to(dev)
+        _, mean, rstd = ops.k_layernorm_fwd(xd, None, None, 1e-5, add=ad, side=side, grid_r=r if r > 1 else 1)
+        slot = -1
+        if ad is not None:
+            slot = len(dadd)
+            dadd.append(torch.zeros(r * r, D, device=dev))
+        items.append((dy.to(dev), mean, rstd, ad, slot))
+        ops.k_layernorm_bwd(dy.to(dev), xd, mean, rstd, add=ad, side=side, grid_r=r if r > 1 else 1, dx_acc=seq_acc)
+    dx = acc0.clone().to(dev) if with_acc else torch.empty(rows, D, device=dev)
+    ops.k_layernorm_bwd_multi(xd, items, side, r if r > 1 else 1, dx, with_acc, dadd)
+    assert rel_err(dx, ref_dx) < TOL[name]
+    assert rel_err(dx, seq_acc) < 2e-6                       # same arithmetic, different summation order across layers
+    k = 0
+    for a in ars:
+        if a is not None:
+            assert rel_err(dadd[k], a.grad) < TOL[name]
+            k += 1

@@ -190,3 +190,30 @@ if "epi" in only:
         emit(kernel="gemm_p5 epilogue", shape=name, check="p5 == 8-wave kernel, bit for bit (first 4096 rows)",
              equal=bool(torch.equal(o8, out[:4096])))
         del a, w, out, kw
+
+if "lnmulti" in only:
+    # the 13 SVA layers' LayerNorm backwards of the 9216-token tower: layer by layer vs cmb_layernorm_bwd_multi
+    rows, D, side, r, Ln = B * 9216, 1024, 96, 4, 13
+    x = rn(rows, D)
+    items, dys = [], []
+    for l in range(Ln):
+        pos = rn(r * r, D, dtype=f32)
+        _, mean, rstd = ops.k_layernorm_fwd(x, None, None, 1e-5, add=pos, side=side, grid_r=r)
+        dys.append(rn(rows, D))
+        items.append((dys[-1], mean, rstd, pos, l))
+    acc = torch.zeros(rows, D, device=dev, dtype=f32)
+
+    def seq():
+        for dn, mean, rstd, pos, _ in items:
+            ops.k_layernorm_bwd(dn, x, mean, rstd, add=pos, side=side, grid_r=r, dx_acc=acc, want_dadd=True)
+    us = timeit(seq, iters=5)
+    emit(kernel="layernorm_bwd x13 (layer by layer, fp32 accumulator)", shape=f"{rows}x{D}", us=round(us, 1),
+         tbps=round(rows * D * 12 * Ln / us / 1e6, 2))
+    dadd = [torch.zeros(r * r, D, device=dev) for _ in range(Ln)]
+    for chunk in (7, 4):
+        L.knob_set(L.KNOB_LN_MULTI_CHUNK, chunk)
+        us = timeit(lambda: ops.k_layernorm_bwd_multi(x, items, side, r, acc, False, dadd), iters=5)
+        nl = -(-Ln // chunk)
+        emit(kernel="layernorm_bwd_multi", shape=f"{rows}x{D} x{Ln} layers", chunk=chunk, us=round(us, 1),
+             tbps=round(rows * D * (2 * Ln + 2 * nl + 8 * nl - 4) / us / 1e6, 2))
+    L.knob_set(L.KNOB_LN_MULTI_CHUNK, 7)
