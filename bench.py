@@ -52,6 +52,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md)
 # forward GFLOP per image of the release-8B path (BASELINE.md §2 / SURVEY.md §8d)
 TOWER_GFLOP = 381.9 + 666.4 + 1785.7 + 6334.9
 SVA_SIDE_GFLOP = 939.9
+# executed but not GEMM launches, per image: tower attention 4 N^2 d per head and layer (CLIP 32.7 + SigLIP 66.1 + DINOv2 131.0 GFLOP),
+# depthwise 7x7 98 FLOP x 324 M outputs (31.8), absorbed SVA kernels' 16 x 16 x 1024 products forward + backward x 13 layers (19.7)
+EXEC_NON_GEMM_TFLOP_PER_IMAGE = (32.7 + 66.1 + 131.0 + 31.8 + 19.7) / 1e3
 
 
 def parse():
@@ -96,6 +99,20 @@ def parse():
                     help="--unfreeze_mm_vision_tower of the reference (SURVEY.md §8f N4): the four towers train too (fp32 master "
                          "parameters, autograd operators); NOT the headline line — the release recipe keeps them frozen")
     ap.add_argument("--llm-layers", type=int, default=None, help="debug only: fewer decoder layers (marks the line INVALID)")
+    ap.add_argument("--stage", choices=["pretrain", "finetune"], default="pretrain",
+                    help="pretrain (the headline: SVA + projectors train, LLM + towers frozen: scripts/cambrian/pretrain_cambrian_8b.sh) "
+                         "or finetune (scripts/cambrian/finetune_cambrian_8b.sh: the whole LLM trains too — 8 B parameters, "
+                         "activation re-computation on, default batch 4; NOT the headline line)")
+    ap.add_argument("--grad-ckpt", action="store_true",
+                    help="activation re-computation of the decoder layers and the in-LLM SVA layers (the reference's "
+                         "--gradient_checkpointing True / fsdp_config.json:9; implied by --stage finetune)")
+    ap.add_argument("--tower-recompute", action="store_true",
+                    help="with --unfreeze-towers: per-block activation re-computation inside the four towers")
+    ap.add_argument("--bucket-mb", type=float, default=64.0, help="gradient bucket size of GradSync / ZeRO-2 (MiB)")
+    ap.add_argument("--comm-only", action="store_true",
+                    help="no model step: run only the gradient-exchange collectives of the configured parameter set (GradSync "
+                         "all-reduce, or the ZeRO-2 reduce-scatter + all-gather with --zero2) for --steps steps and print the bus "
+                         "bandwidth per bucket — the communication breakdown beside a scaling curve")
     return ap.parse_args()
 
 
@@ -112,7 +129,8 @@ PRESETS = {
 }
 
 
-def build_model(dev, llm_layers=None, preset="8b", unfreeze_towers=False):
+def build_model(dev, llm_layers=None, preset="8b", unfreeze_towers=False, stage="pretrain", grad_ckpt=False,
+                tower_recompute=False):
     from cambrian_amd.model.language_model.cambrian_llama import (CambrianLlamaForCausalLM, apply_release_8b_vision_config,
                                                                 llama3_8b_config)
     geo = dict(PRESETS[preset]["llm"])
@@ -145,7 +163,14 @@ def build_model(dev, llm_layers=None, preset="8b", unfreeze_towers=False):
     if unfreeze_towers:
         train_keys += ("vision_tower_aux_list",)
     for n, p in model.named_parameters():
-        p.requires_grad_(any(k in n for k in train_keys))
+        # finetune stage (train_fsdp.py:1677-1695 with tune_mm_mlp_adapter off): everything but the towers trains
+        p.requires_grad_(any(k in n for k in train_keys) or (stage == "finetune" and "vision_tower_aux_list" not in n))
+    cfg.gradient_checkpointing = bool(grad_ckpt or stage == "finetune")
+    if unfreeze_towers and tower_recompute:
+        for t in model.model.vision_tower_aux_list:
+            for m in t.modules():          # TrainableViT / TrainableConvNeXt: per-block activation re-computation
+                if hasattr(m, "recompute"):
+                    m.recompute = True
     return model, cfg
 
 
@@ -399,6 +424,93 @@ def self_spawn(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def comm_only(args, rank, world, dev, params, opt, sync):
+    """--comm-only: the gradient exchange of the configured parameter set alone — GradSync's bucketed all-reduce (default) or
+    ZeRO-2's reduce-scatter + all-gather — timed per bucket with events on the collectives' completion, K steps.  Bus bandwidth
+    per bucket as RCCL's tests define it: all-reduce 2 (N - 1) / N x bytes / time; reduce-scatter / all-gather (N - 1) / N."""
+    import torch.distributed as dist
+
+    def _sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+    nbytes_total = sum(p.numel() * p.element_size() for p in params)
+    rows = []
+    if sync is not None:
+        for b in sync.buckets:
+            b.flat.normal_()
+    _sync()
+
+    def one_step(record):
+        t_step = time.perf_counter()
+        if sync is not None:
+            for i, b in enumerate(sync.buckets):
+                t0 = time.perf_counter()
+                if world > 1 or dist.is_initialized():
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=sync.group)
+                _sync()
+                if record:
+                    rows.append(("all_reduce", i, b.flat.numel() * b.flat.element_size(), time.perf_counter() - t0))
+        else:   # ZeRO-2
+            for i, b in enumerate(opt.buckets):
+                t0 = time.perf_counter()
+                if world > 1:
+                    dist.reduce_scatter_tensor(b.grad_shard, b.flat_grad, op=dist.ReduceOp.SUM, group=opt.group)
+                _sync()
+                t1 = time.perf_counter()
+                if world > 1:
+                    dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=opt.group)
+                _sync()
+                if record:
+                    nb = b.flat_grad.numel() * b.flat_grad.element_size()
+                    rows.append(("reduce_scatter", i, nb, t1 - t0))
+                    rows.append(("all_gather", i, nb, time.perf_counter() - t1))
+        return time.perf_counter() - t_step
+
+    for _ in range(args.warmup):
+        one_step(False)
+    if world > 1:
+        dist.barrier()
+    _sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    _sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        per = {}
+        for kind, i, nb, dt in rows:
+            e = per.setdefault((kind, i), [nb, 0.0, 0])
+            e[1] += dt
+            e[2] += 1
+        fac = {"all_reduce": 2.0 * (world - 1) / world, "reduce_scatter": (world - 1) / world, "all_gather": (world - 1) / world}
+        buckets = [{"collective": k[0], "bucket": k[1], "bytes": v[0], "avg_ms": v[1] / v[2] * 1e3,
+                    "bus_gb_per_s": (fac[k[0]] * v[0] / (v[1] / v[2]) / 1e9) if world > 1 else None} for k, v in sorted(per.items())]
+        tot_bytes = sum(b["bytes"] for b in buckets if b["collective"] != "all_gather")
+        line = {"metric": "gradient exchange only (NOT the headline metric): ms per step of the configured parameter set's collectives",
+                "value": elapsed / args.steps * 1e3, "unit": "ms/step", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+                "dtype": "fp32 gradients of the SVA / projector parameters" + (", bf16 of the LLM" if args.stage == "finetune" else ""),
+                "data": "synthetic",
+                "config": {"workload": f"--comm-only, stage {args.stage}: {'ZeRO-2 reduce-scatter + all-gather' if sync is None else 'GradSync all-reduce'}"
+                                       f" of {len(params)} tensors / {nbytes_total / 2 ** 30:.2f} GiB of gradients in {len(buckets)} collectives of "
+                                       f"<= {args.bucket_mb:g} MiB", "parallelism": f"dp{world}" + ("+zero2" if sync is None else ""),
+                           "bucket_mb": args.bucket_mb, "gradient_bytes": nbytes_total, "NOT_HEADLINE": "communication only"},
+                "buckets": buckets,
+                "aggregate_bus_gb_per_s": ((fac["all_reduce"] if sync is not None else fac["reduce_scatter"]) * tot_bytes
+                                           / (elapsed / args.steps) / 1e9) if world > 1 else None}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -423,7 +535,8 @@ def main():
     global ABSORB_KV_ON
     ABSORB_KV_ON = bool(_vs.ABSORB_KV)
 
-    model, cfg = build_model(dev, args.llm_layers, args.preset, args.unfreeze_towers)
+    model, cfg = build_model(dev, args.llm_layers, args.preset, args.unfreeze_towers, args.stage, args.grad_ckpt,
+                             args.tower_recompute)
     cfg.fp8_projections = bool(args.fp8_projections)
     params = [p for p in model.parameters() if p.requires_grad]
     z3_units = None
@@ -440,16 +553,18 @@ def main():
         z3_units = zero3_wrap(mods)
         rest = [p for p in params if id(p) not in in_units]
         opt = torch.optim.AdamW(zero3_parameters(z3_units) + rest, lr=1e-4, weight_decay=0.0, fused=True)
-        sync = GradSync(rest) if rest else None
+        sync = GradSync(rest, bucket_mb=args.bucket_mb) if rest else None
     elif args.zero2:
         from cambrian_amd.train.zero import Zero2AdamW
-        opt, sync = Zero2AdamW(params, lr=1e-4, weight_decay=0.0), None
+        opt, sync = Zero2AdamW(params, lr=1e-4, weight_decay=0.0, bucket_mb=args.bucket_mb), None
     else:
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
-        sync = GradSync(params)
+        sync = GradSync(params, bucket_mb=args.bucket_mb)
+    if args.comm_only:
+        return comm_only(args, rank, world, dev, params, opt, sync)
     if args.batch <= 0:   # default: what fits the device with headroom
         total_gb = torch.cuda.get_device_properties(dev).total_memory / 2 ** 30
-        args.batch = 24 if (total_gb >= 280 and args.preset == "8b") else 16
+        args.batch = 4 if args.stage == "finetune" else (24 if (total_gb >= 280 and args.preset == "8b") else 16)
     B = args.batch
     pos0 = cfg.image_position
 
@@ -627,6 +742,17 @@ def main():
             line["config"]["NOT_HEADLINE"] = ("--unfreeze_mm_vision_tower (SURVEY.md §8f N4): the towers train; the release recipe "
                                               "and the headline line keep them frozen")
             line["config"]["trainable_parameters"] = int(sum(p.numel() for p in params))
+        if args.stage == "finetune":
+            line["config"]["NOT_HEADLINE"] = ("finetune stage (scripts/cambrian/finetune_cambrian_8b.sh): the whole LLM trains "
+                                              "(activation re-computation on); the headline metric is quoted on the pre-training stage")
+            line["config"]["workload"] = line["config"]["workload"].replace(
+                "pre-training stage (SVA+projectors train, LLM+towers frozen)", "FINETUNE stage (LLM + SVA + projectors train, towers frozen)")
+            line["config"]["trainable_parameters"] = int(sum(p.numel() for p in params))
+            line["config"]["gradient_buckets"] = (len(sync.buckets) if sync is not None else len(getattr(opt, "buckets", [])))
+        if cfg.gradient_checkpointing:
+            line["config"]["activation_recomputation"] = "decoder layers + in-LLM SVA layers (non-reentrant checkpoint)"
+        if args.unfreeze_towers and args.tower_recompute:
+            line["config"]["tower_recompute"] = "per block"
         if args.llm_layers is not None:
             line["config"]["INVALID"] = f"debug run with {args.llm_layers} decoder layers"
         if prof:
@@ -691,6 +817,15 @@ def main():
                     "tflop_per_step": fall / gemm_pass_steps / 1e12,
                     "from": f"{gemm_pass_steps} extra profiled steps after the timed region (an event pair around every own bf16 "
                             "GEMM launch: 128- and 256-tile kernels, split-K wgrad GEMMs with their reduce kernels)"}
+                if "region" in line["roofline"]:
+                    # what this build EXECUTES in the region: every own GEMM launch of the step is inside it
+                    # (measured 2 M N K sums) + the towers' attention (4 N^2 d per head and layer), the depthwise
+                    # convolutions (98 FLOP per output) and the absorbed SVA kernels' 16 x 16 x 1024 products — per image
+                    # 0.230 + 0.032 + 0.020 TFLOP — next to the reference-algorithm count the `frac` above is quoted on
+                    reg = line["roofline"]["region"]
+                    ex = fall / gemm_pass_steps / 1e12 + EXEC_NON_GEMM_TFLOP_PER_IMAGE * B
+                    reg["executed_tflop_per_step"] = ex
+                    reg["executed_frac"] = ex / (reg["ms_per_step"] * 1e-3) / MFMA_BF16_PEAK_TFLOPS if reg["ms_per_step"] > 0 else 0.0
             if calibration is not None:
                 line["roofline"]["calibration"] = calibration
         if prof_all and args.gemm_report:

@@ -22,6 +22,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint as _checkpoint
 
 try:  # HF config class only (no HF modelling code is used)
     from transformers import LlamaConfig
@@ -336,8 +337,16 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
         if sva is not None and not getattr(cfg, "connector_only", True):
             start, stride = cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers
             hook_layers = {start + k * stride: k for k in range(len(self.vision_sampler_layers))}  # :170-172
+        # Activation re-computation (the reference: `--gradient_checkpointing True` in the finetune scripts,
+        # scripts/cambrian/finetune_cambrian_8b.sh; FSDP wraps and checkpoints every decoder layer, fsdp_config.json:9, and
+        # cambrian_llama.py:189-196 checkpoints the in-LLM SVA layers): a layer keeps only its input, its forward runs a second
+        # time inside the backward.  Non-reentrant, so the custom autograd operators' saved tensors are the recomputed ones.
+        ckpt = bool(getattr(cfg, "gradient_checkpointing", False)) and torch.is_grad_enabled() and kv_out is None
         for i, layer in enumerate(self.layers):
-            hidden = layer(hidden, cos, sin, attn_mask, kv_out)
+            if ckpt and hidden.requires_grad:
+                hidden = _checkpoint(layer, hidden, cos, sin, attn_mask, None, use_reentrant=False)
+            else:
+                hidden = layer(hidden, cos, sin, attn_mask, kv_out)
             if i in hook_layers:
                 if isinstance(sva, SvaDynamic):
                     hidden = self._sva_hook_dynamic(hidden, hook_layers[i], sva)
@@ -376,8 +385,12 @@ class CambrianLlamaModel(CambrianMetaModel, LlamaBackbone):
         q2 = ops.gather_query_rows(hidden, p0, side, link)                             # [B*576, H]
         q2 = ops.region_mark(q2, span, "b1")
         feats = [f if f.dtype == q2.dtype else f.to(q2.dtype) for f in sva.feats]      # :186
-        out = self.vision_sampler_layers[k].forward_fused(q2, sva.ctx_b.to(q2.dtype), feats, sva.masks_u8, sva.holders,
-                                                         sva.B, side)
+        sampler = self.vision_sampler_layers[k]
+        if bool(getattr(cfg, "gradient_checkpointing", False)) and torch.is_grad_enabled() and q2.requires_grad:
+            out = _checkpoint(sampler.forward_fused, q2, sva.ctx_b.to(q2.dtype), feats, sva.masks_u8, sva.holders, sva.B, side,
+                              use_reentrant=False)                                     # cambrian_llama.py:189-196
+        else:
+            out = sampler.forward_fused(q2, sva.ctx_b.to(q2.dtype), feats, sva.masks_u8, sva.holders, sva.B, side)
         out = ops.region_mark(out, span, "b0")
         hidden = ops.scatter_query_rows(hidden, out, p0, side, link)
         ops.region_fwd_end(span)

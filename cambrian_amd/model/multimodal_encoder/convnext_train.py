@@ -20,6 +20,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
 
 from ... import lib as L
 from ... import ops
@@ -86,6 +87,7 @@ class TrainableConvNeXt(nn.Module):
         if dtype != torch.bfloat16:
             raise L.CambrianAmdError("trainable towers compute in bf16 (fp32 masters)")
         self.cfg, self.compute_dtype = cfg, dtype
+        self.recompute = False   # per-block activation re-computation (bench.py --tower-recompute)
         self.p = nn.ParameterDict({_key(k): nn.Parameter(v.detach().to(device=device, dtype=torch.float32).clone())
                                    for k, v in canonical.items()})
 
@@ -94,6 +96,17 @@ class TrainableConvNeXt(nn.Module):
 
     def canonical_state(self) -> Dict[str, torch.Tensor]:
         return {k.replace("__", "."): v.detach() for k, v in self.p.items()}
+
+    def _block(self, s: int, b: int, x: torch.Tensor, B: int, H: int, c: int) -> torch.Tensor:
+        """One ConvNeXt block on NHWC rows [B*H*H, c] (timm ConvNeXtBlock: dw 7x7 -> LN -> fc1 + GELU -> fc2 (* gamma) + x)."""
+        cfg, dt = self.cfg, self.compute_dtype
+        g = lambda n: self.P(f"stages.{s}.blocks.{b}.{n}")  # noqa: E731
+        y = DwConv7x7Fn.apply(x.view(B, H, H, c), g("dw.weight").reshape(c, 49).t(), g("dw.bias")).view(-1, c)
+        yn = ops.layernorm(y, g("ln.weight"), g("ln.bias"), cfg.ln_eps)
+        h = ops.linear(yn, g("fc1.weight"), g("fc1.bias"), act=L.ACT_GELU_ERF)
+        if cfg.layer_scale:
+            return x + ops.linear(h, g("fc2.weight"), g("fc2.bias")) * g("gamma").to(dt)
+        return ops.linear(h, g("fc2.weight"), g("fc2.bias"), residual=x)
 
     def forward_stages(self, images: torch.Tensor) -> List[torch.Tensor]:
         cfg, dt = self.cfg, self.compute_dtype
@@ -117,14 +130,10 @@ class TrainableConvNeXt(nn.Module):
                 wd = g("conv.weight").permute(0, 2, 3, 1).reshape(c, 4 * cp)          # (dy, dx, cin) column order
                 x = ops.linear(cols, wd, g("conv.bias"))
             for b in range(depth):
-                g = lambda n: self.P(f"stages.{s}.blocks.{b}.{n}")  # noqa: E731
-                y = DwConv7x7Fn.apply(x.view(B, H, H, c), g("dw.weight").reshape(c, 49).t(), g("dw.bias")).view(-1, c)
-                yn = ops.layernorm(y, g("ln.weight"), g("ln.bias"), cfg.ln_eps)
-                h = ops.linear(yn, g("fc1.weight"), g("fc1.bias"), act=L.ACT_GELU_ERF)
-                if cfg.layer_scale:
-                    x = x + ops.linear(h, g("fc2.weight"), g("fc2.bias")) * g("gamma").to(dt)
+                if self.recompute and torch.is_grad_enabled():   # per-block activation re-computation (flag-controlled)
+                    x = checkpoint(self._block, s, b, x, B, H, c, use_reentrant=False)
                 else:
-                    x = ops.linear(h, g("fc2.weight"), g("fc2.bias"), residual=x)
+                    x = self._block(s, b, x, B, H, c)
             outs.append(x.view(B, H, H, c))
         return outs
 

@@ -28,6 +28,7 @@ from typing import Callable, Dict, Optional
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
 
 from ... import lib as L
 from ... import ops
@@ -61,6 +62,7 @@ class TrainableViT(nn.Module):
         native-resolution parameter."""
         super().__init__()
         self.pos_fn = pos_fn
+        self.recompute = False   # per-block activation re-computation (set by the tower wrapper / bench.py --tower-recompute)
         if dtype != torch.bfloat16:
             raise L.CambrianAmdError("trainable towers compute in bf16 (fp32 masters)")
         self.cfg = cfg
@@ -85,6 +87,41 @@ class TrainableViT(nn.Module):
     def has(self, name: str) -> bool:
         return _key(name) in self.p
 
+    def _block(self, l: int, x: torch.Tensor, B: int, N: int) -> torch.Tensor:
+        """One transformer block on token-major rows [B*N, D] (HF CLIPEncoderLayer / Dinov2Layer / timm Block)."""
+        cfg, dt = self.cfg, self.compute_dtype
+        D, H, hd = cfg.hidden_size, cfg.num_heads, cfg.head_dim
+        act = _ACT[cfg.act]
+        scale = 1.0 / math.sqrt(hd)
+        Fm = cfg.mlp_dim
+        Fp = (Fm + 63) // 64 * 64
+        g = lambda n: self.P(f"layers.{l}.{n}")  # noqa: E731
+        h = ops.layernorm(x, g("ln1.weight"), g("ln1.bias"), cfg.ln_eps)
+        wqkv = torch.cat([g("q.weight"), g("k.weight"), g("v.weight")], 0)
+        bqkv = torch.cat([g("q.bias"), g("k.bias"), g("v.bias")], 0)
+        qkv = ops.linear(h, wqkv, bqkv).view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)     # [3,B,H,N,hd] views
+        a = ops.vit_attention(qkv[0], qkv[1], qkv[2], scale)                            # [B,H,N,hd]
+        a = a.transpose(1, 2).reshape(B * N, D)
+        if cfg.layerscale:
+            x = x + ops.linear(a, g("proj.weight"), g("proj.bias")) * g("ls1").to(dt)
+        else:
+            x = ops.linear(a, g("proj.weight"), g("proj.bias"), residual=x)
+        h = ops.layernorm(x, g("ln2.weight"), g("ln2.bias"), cfg.ln_eps)
+        if cfg.act == "swiglu":                   # Dinov2SwiGLUFFN: silu(x1) * x2, x1 | x2 = weights_in(x).chunk(2)
+            f = ops.linear(h, g("fc1.weight"), g("fc1.bias"))
+            f = ops.swiglu(f[:, :Fm], f[:, Fm:])
+            w2 = g("fc2.weight")
+        else:
+            w1, b1, w2 = g("fc1.weight"), g("fc1.bias"), g("fc2.weight")
+            if Fp != Fm:                           # zero rows / columns: act(0) = 0 for every activation used here
+                w1, b1, w2 = F.pad(w1, (0, 0, 0, Fp - Fm)), F.pad(b1, (0, Fp - Fm)), F.pad(w2, (0, Fp - Fm))
+            f = ops.linear(h, w1, b1, act=act)
+        if cfg.layerscale:
+            x = x + ops.linear(f, w2, g("fc2.bias")) * g("ls2").to(dt)
+        else:
+            x = ops.linear(f, w2, g("fc2.bias"), residual=x)
+        return x
+
     # ---- forward -------------------------------------------------------------------------------------------------
     def forward(self, images: torch.Tensor) -> torch.Tensor:
         cfg, dt = self.cfg, self.compute_dtype
@@ -107,36 +144,12 @@ class TrainableViT(nn.Module):
         x = x.reshape(B * N, D)
         if cfg.pre_ln:
             x = ops.layernorm(x, self.P("pre_ln.weight"), self.P("pre_ln.bias"), cfg.ln_eps)
-        act = _ACT[cfg.act]
-        scale = 1.0 / math.sqrt(hd)
-        Fm = cfg.mlp_dim
-        Fp = (Fm + 63) // 64 * 64
         for l in range(self.nl):
-            g = lambda n: self.P(f"layers.{l}.{n}")  # noqa: E731
-            h = ops.layernorm(x, g("ln1.weight"), g("ln1.bias"), cfg.ln_eps)
-            wqkv = torch.cat([g("q.weight"), g("k.weight"), g("v.weight")], 0)
-            bqkv = torch.cat([g("q.bias"), g("k.bias"), g("v.bias")], 0)
-            qkv = ops.linear(h, wqkv, bqkv).view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)     # [3,B,H,N,hd] views
-            a = ops.vit_attention(qkv[0], qkv[1], qkv[2], scale)                            # [B,H,N,hd]
-            a = a.transpose(1, 2).reshape(B * N, D)
-            if cfg.layerscale:
-                x = x + ops.linear(a, g("proj.weight"), g("proj.bias")) * g("ls1").to(dt)
+            if self.recompute and torch.is_grad_enabled():
+                # per-block activation re-computation (flag-controlled: `recompute`): a block keeps only its input
+                x = checkpoint(self._block, l, x, B, N, use_reentrant=False)
             else:
-                x = ops.linear(a, g("proj.weight"), g("proj.bias"), residual=x)
-            h = ops.layernorm(x, g("ln2.weight"), g("ln2.bias"), cfg.ln_eps)
-            if cfg.act == "swiglu":                   # Dinov2SwiGLUFFN: silu(x1) * x2, x1 | x2 = weights_in(x).chunk(2)
-                f = ops.linear(h, g("fc1.weight"), g("fc1.bias"))
-                f = ops.swiglu(f[:, :Fm], f[:, Fm:])
-                w2 = g("fc2.weight")
-            else:
-                w1, b1, w2 = g("fc1.weight"), g("fc1.bias"), g("fc2.weight")
-                if Fp != Fm:                           # zero rows / columns: act(0) = 0 for every activation used here
-                    w1, b1, w2 = F.pad(w1, (0, 0, 0, Fp - Fm)), F.pad(b1, (0, Fp - Fm)), F.pad(w2, (0, Fp - Fm))
-                f = ops.linear(h, w1, b1, act=act)
-            if cfg.layerscale:
-                x = x + ops.linear(f, w2, g("fc2.bias")) * g("ls2").to(dt)
-            else:
-                x = ops.linear(f, w2, g("fc2.bias"), residual=x)
+                x = self._block(l, x, B, N)
         if cfg.final_ln:
             x = ops.layernorm(x, self.P("final_ln.weight"), self.P("final_ln.bias"), cfg.ln_eps)
         x = x.view(B, N, D)

@@ -1172,8 +1172,8 @@ def token_mean(x, holder=None):
 
 class EmbedSpliceFn(torch.autograd.Function):
     """inputs_embeds of the static path: embedding gather + newline column + visual splice in one kernel
-    (cambrian_arch.py:413-420,457-490).  Gradients flow to feat and newline; the embedding table is frozen
-    in the pre-training stage (train_fsdp.py:1677-1685)."""
+    (cambrian_arch.py:413-420,457-490).  Gradients flow to feat and newline, and — finetune stage — to the embedding table
+    (frozen in the pre-training stage: train_fsdp.py:1677-1685)."""
 
     @staticmethod
     def forward(ctx, ids, table, feat, newline, side: int, image_token: int):
@@ -1190,25 +1190,33 @@ class EmbedSpliceFn(torch.autograd.Function):
                                            featc.data_ptr(), side, nl.data_ptr(), out.data_ptr(), pos.data_ptr(),
                                            L.stream_ptr(feat.device))
         L.check(rc, "cmb_embed_splice_fwd")
-        ctx.cfg = (B, S, H, side, dt, newline.dtype)
-        ctx.save_for_backward(pos)
+        ctx.cfg = (B, S, H, side, dt, newline.dtype, V, table.dtype, image_token)
+        ctx.save_for_backward(pos, idc)
         ctx.mark_non_differentiable(pos)
         return out, pos
 
     @staticmethod
     def backward(ctx, dout, _dpos):
-        (pos,) = ctx.saved_tensors
-        B, S, H, side, dt, nl_dtype = ctx.cfg
-        if ctx.needs_input_grad[1]:
-            raise L.CambrianAmdError("training the embedding table through EmbedSpliceFn is not implemented "
-                                     "(the pre-training stage freezes it: train_fsdp.py:1677-1685)")
+        pos, ids = ctx.saved_tensors
+        B, S, H, side, dt, nl_dtype, V, tab_dtype, image_token = ctx.cfg
         dout = _as_dtype_contig(dout, dt)
+        dtable = None
+        if ctx.needs_input_grad[1]:
+            # finetune stage (the embedding table trains): nn.Embedding's backward for the TEXT rows — every position outside
+            # the visual span [p_b, p_b + side (side + 1)) gathers table[ids'] (stock index_add_, fp32 accumulation)
+            t = torch.arange(S, device=dout.device)[None]
+            p_b = pos.to(torch.int64)[:, None]
+            text = (p_b < 0) | (t < p_b) | (t >= p_b + side * (side + 1))
+            idx = torch.where(ids == image_token, torch.zeros_like(ids), ids)[text]
+            dtable = torch.zeros((V, H), dtype=torch.float32, device=dout.device)
+            dtable.index_add_(0, idx, dout[text].float())
+            dtable = dtable.to(tab_dtype)
         dfeat = torch.empty((B, side * side, H), dtype=dt, device=dout.device)
         dnl = torch.zeros((H,), dtype=torch.float32, device=dout.device)
         rc = L.load().cmb_embed_splice_bwd(L.dtype_code(dt), dout.data_ptr(), pos.data_ptr(), B, S, H, side,
                                            dfeat.data_ptr(), dnl.data_ptr(), L.stream_ptr(dout.device))
         L.check(rc, "cmb_embed_splice_bwd")
-        return None, None, dfeat, dnl.to(nl_dtype), None, None
+        return None, dtable, dfeat, dnl.to(nl_dtype), None, None
 
 
 def embed_splice(ids, table, feat, newline, side: int, image_token: int = -200):

@@ -334,3 +334,47 @@ def test_text_only_early_out(dev, monkeypatch):
     assert r[0] is ids and r[4] is None and r[6] is None and len(r) == 10
     out = model(input_ids=ids, labels=ids)
     assert out.logits.shape == (2, 16, 300) and torch.isfinite(out.loss)
+
+
+@pytest.mark.parametrize("ckpt", [False, True])
+@pytest.mark.parametrize("name,dt,tol_logits,tol_grad", [("fp32", torch.float32, 1e-3, 5e-3), ("bf16", torch.bfloat16, 2e-2, 6e-2)])
+def test_finetune_stage_every_decoder_gradient(dev, monkeypatch, name, dt, tol_logits, tol_grad, ckpt):
+    """The FINETUNE stage (scripts/cambrian/finetune_cambrian_8b.sh: the whole LLM trains, towers frozen):
+    every decoder weight — embeddings, q / k / v / o, gate / up / down, the RMSNorm gains, lm_head — requires grad, so the
+    decoder runs its trainable-projection path (separate projections, own flash attention, RMSNorm backward with dw) instead of
+    the frozen-weight GEMM fusions; logits, loss and the gradient of EVERY trainable tensor against oracle/{arch,llama}.py
+    differentiated by autograd.  ``ckpt``: with activation re-computation of the decoder layers and the in-LLM SVA layers
+    (config.gradient_checkpointing, cambrian_llama.py:189-196 / fsdp_config.json:9) — the same numbers."""
+    from cambrian_amd.train.data_layout import synthetic_batch
+    model, cfg, towers = _build(dev, dt, monkeypatch)
+    for n, p in model.named_parameters():
+        p.requires_grad_(True)
+    cfg.gradient_checkpointing = ckpt
+    batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
+                            image_res=[56, 64], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
+    ref_loss, ref_logits, p = _oracle_run(model, cfg, towers, batch)
+    ref_loss.backward()
+    out = model(input_ids=batch["input_ids"].to(dev), attention_mask=batch["attention_mask"].to(dev),
+                position_ids=batch["position_ids"].to(dev), labels=batch["labels"].to(dev),
+                images=[i.to(dev, dt) for i in batch["images"]],
+                image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
+                image_sizes=batch["image_sizes"])
+    e = rel_err(out.logits, ref_logits)
+    assert e < tol_logits, f"logits rel err {e}"
+    out.loss.backward()
+    assert abs(out.loss.item() - ref_loss.item()) < tol_logits * max(1.0, abs(ref_loss.item()))
+    worst, n_dec, n_all = ("", 0.0), 0, 0
+    for n, q in model.named_parameters():
+        assert q.grad is not None, n
+        g_ref = p[n].grad
+        if g_ref is None or g_ref.abs().max() == 0:
+            continue
+        err = rel_err(q.grad, g_ref)
+        n_all += 1
+        n_dec += int(".layers." in n and "vision_sampler" not in n or n.startswith("lm_head") or "embed_tokens" in n
+                     or n == "model.norm.weight")
+        if err > worst[1]:
+            worst = (n, err)
+    assert n_dec >= 4 * 9 + 3, n_dec          # 4 decoder layers x (q, k, v, o, gate, up, down, 2 norms) + embeddings, final norm, lm_head
+    assert n_all > n_dec + 50
+    assert worst[1] < tol_grad, f"worst gradient {worst}"
