@@ -636,7 +636,7 @@ def main():
         warm_left = max(0, warm_left - 1)
         torch.cuda.synchronize()
         tc = time.perf_counter()
-        rows = ops.calibrate_gemm_dispatch(census.top(8), iters=3, device=dev)
+        rows = ops.calibrate_gemm_dispatch(census.top(20, min_tiles=128), iters=3, device=dev)
         torch.cuda.synchronize()
         calibration = {"shapes": rows, "wall_ms": (time.perf_counter() - tc) * 1e3,
                        "what": "per (M, N, K, act): min of 3 launches of gemm_nt_p5_kernel (2590) vs gemm_nt_256_kernel (2560) "

@@ -123,31 +123,33 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(int act, const T* __restri
   }
 }
 
-// out[b, :] = mean_t x[b, t, :]
+// out[b, :] = mean_t x[b, t, :].  A workgroup owns 64 columns of one image (8 lanes x 16 bytes = one 128-byte line per token
+// row) and splits the tokens over its 32 lane groups; round 4: the first version gave a workgroup 512 columns — 48 workgroups
+// for the release shape [24, 576, 1024], 44 us = 0.10 of the HBM peak (profiles/r03_hbm_kernels_table.md) — now 384.
 template <typename T>
 __global__ void __launch_bounds__(256) token_mean_kernel(const T* __restrict__ x, int Tn, int D, T* __restrict__ out) {
-  __shared__ float red[4][512];
+  __shared__ float red[32][65];
   const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cv = blockIdx.x * 64 + lane;
+  const int cl = threadIdx.x & 7, tg = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + cl * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (cv * 8 < D) {
-    for (int t = wave; t < Tn; t += 4) {
+  if (c0 < D) {
+    for (int t = tg; t < Tn; t += 32) {
       float v[8];
-      Vec8<T>::load(x + ((int64_t)b * Tn + t) * D + cv * 8, v);
+      Vec8<T>::load(x + ((int64_t)b * Tn + t) * D + c0, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[e];
+  for (int e = 0; e < 8; ++e) red[tg][cl * 8 + e] = acc[e];
   __syncthreads();
-  if (wave == 0 && cv * 8 < D) {
-    float o[8];
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && col < D) {
+    float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      o[e] = (red[0][lane * 8 + e] + red[1][lane * 8 + e] + red[2][lane * 8 + e] + red[3][lane * 8 + e]) / (float)Tn;
-    Vec8<T>::store(out + (int64_t)b * D + cv * 8, o);
+    for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+    out[(int64_t)b * D + col] = (T)(s / (float)Tn);
   }
 }
 
@@ -439,7 +441,7 @@ extern "C" int cmb_act_bwd(int dtype, int32_t act, const void* dy, const void* p
 extern "C" int cmb_token_mean_fwd(int dtype, const void* x, int64_t B, int64_t Tn, int64_t D, void* out, void* stream) {
   if (!x || !out || B < 0 || Tn <= 0 || D <= 0 || (D & 7)) return CMB_ERR_BAD_ARG;
   if (B == 0) return CMB_OK;
-  dim3 grid((unsigned)((D + 511) / 512), (unsigned)B);
+  dim3 grid((unsigned)((D + 63) / 64), (unsigned)B);
   DT_SWITCH(dtype, hipLaunchKernelGGL(token_mean_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
                                       (int)Tn, (int)D, (T*)out));
   CMB_CHECK_LAUNCH();

@@ -291,19 +291,22 @@ static int policy_lookup(int64_t M, int64_t N, int64_t K, int act) {
   return 0;
 }
 
-// Where the register-buffered 4-wave kernel is the default 256 x 256 kernel (measured, profiles/r02_gemm_lab.md): whole
-// tile columns (a ragged one leaves through its generic epilogue and drains the DMA pipeline: N = 1152 runs 20-40 %
-// behind the 8-wave kernel), no pre-activation copy (generic epilogue again), and more than one round of items per CU —
-// its gain is the overlap ACROSS items; a single round with an activation epilogue is 25 % faster on the 8-wave kernel,
-// whose two waves per SIMD interleave the epilogue's dependency chains.
+// Where the register-buffered 4-wave kernel is the default 256 x 256 kernel: whole 128-column halves (round 4: in a last
+// column tile with only its lower half in range the upper waves skip the epilogue; a half that is itself ragged leaves
+// through the generic epilogue and drains the DMA pipeline — N = 1152 used to run 20-40 % behind the 8-wave kernel for that
+// reason), no pre-activation copy (generic epilogue again) and at least 64 tiles.  Rounds 2-3 required more than one round of
+// items per CU (the kernel's gain is the overlap ACROSS items, and a single round with an activation epilogue was 25 %
+// faster on the 8-wave kernel); with round 4's epilogue (compile-time bias / LayerScale / residual variants, packed math) the
+// start-up calibration found it ahead on all 20 hottest shapes of the step including the single-round ones (13824 x 1024 x
+// 1024: 33.0 vs 36.4 us; profiles/r04_lab.md).
 static bool p5_default(const GemmParams& p, int splits) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * splits;
   static long min_tiles = -1;  // CMB_GEMM_P5_MIN_TILES: experiments only
   if (min_tiles < 0) {
     const char* e = getenv("CMB_GEMM_P5_MIN_TILES");
-    min_tiles = e ? atol(e) : 257;
+    min_tiles = e ? atol(e) : 64;
   }
-  return p.N % 256 == 0 && !p.P && tiles >= min_tiles;
+  return p.N % 128 == 0 && !p.P && tiles >= min_tiles;
 }
 
 // Which bf16 kernel a problem takes.  tile_hint / CMB_GEMM_TILE: 0 = the per-shape policy if the host calibrated one for
@@ -351,8 +354,8 @@ static bool tail_split_enabled() {
 }
 static bool map_linear_at(const RowMap& m, int64_t row) { return m.n1 == 0 || row % m.n1 == 0; }
 static int tail_split_rows_mnk(int64_t M, int64_t N) {
-  if (!tail_split_enabled() || N % 256 != 0) return 0;
-  const int64_t tm = (M + 255) / 256, tn = N / 256, T = tm * tn;
+  if (!tail_split_enabled() || N % 128 != 0) return 0;
+  const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, T = tm * tn;
   const int64_t ncu = device_cus();
   if (T <= ncu) return 0;
   const int64_t m1 = ((T / ncu) * ncu) / tn;   // row tiles that fill whole rounds
@@ -393,6 +396,10 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
   p.slab_rows = p.M;
   int splits = d->split_k > 1 ? d->split_k : 1;
+  if (d->act == CMB_ACT_SWIGLU_PAIRS &&
+      (splits > 1 || d->colscale || d->residual || d->pre_out || d->out_dtype != d->dtype || d->N % 16 != 0 || p.batch > 1 ||
+       sizeof(T) == 1))
+    return CMB_ERR_BAD_ARG;   // the gated epilogue writes an N / 2 wide C of the operand dtype and nothing else
   if (p.batch > 1) {
     // batched problems: plain epilogue (alpha / activation / out dtype), no split-K, 16-byte aligned strides
     if (splits > 1 || d->bias || d->colscale || d->residual || d->pre_out || sizeof(T) == 1) return CMB_ERR_BAD_ARG;

@@ -110,6 +110,16 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += bb[e];
   }
+  if constexpr (ACT == CMB_ACT_SWIGLU_PAIRS) {
+    // (gate, up) column pairs -> 4 outputs at columns gn / 2 .. gn / 2 + 3 of an N / 2 wide C; nothing else applies (dispatch)
+    T o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (T)(v[2 * k] * cmb_sigmoid(v[2 * k]) * v[2 * k + 1]);
+    T* cp = reinterpret_cast<T*>(p.C) + row_off(p.c_map, (uint32_t)gm) + (gn >> 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cp[k] = o[k];
+    return;
+  }
   if (p.P) Vec8<T>::store(reinterpret_cast<T*>(p.P) + row_off(p.p_map, (uint32_t)gm) + gn, v);
   if constexpr (ACT == CMB_ACT_GELU_ERF && std::is_same<T, bf16_t>::value) {
 #pragma unroll
@@ -153,6 +163,7 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
     case CMB_ACT_GELU_TANH: f(std::integral_constant<int, CMB_ACT_GELU_TANH>{}); break;
     case CMB_ACT_QUICK_GELU: f(std::integral_constant<int, CMB_ACT_QUICK_GELU>{}); break;
     case CMB_ACT_SILU: f(std::integral_constant<int, CMB_ACT_SILU>{}); break;
+    case CMB_ACT_SWIGLU_PAIRS: f(std::integral_constant<int, CMB_ACT_SWIGLU_PAIRS>{}); break;
     default: f(std::integral_constant<int, CMB_ACT_NONE>{}); break;
   }
 }

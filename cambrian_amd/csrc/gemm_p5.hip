@@ -344,6 +344,7 @@ int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s) {
     case CMB_ACT_GELU_TANH: return launch_p5_act<CMB_ACT_GELU_TANH>(p, splits, s);
     case CMB_ACT_QUICK_GELU: return launch_p5_act<CMB_ACT_QUICK_GELU>(p, splits, s);
     case CMB_ACT_SILU: return launch_p5_act<CMB_ACT_SILU>(p, splits, s);
+    case CMB_ACT_SWIGLU_PAIRS: return launch_p5_act<CMB_ACT_SWIGLU_PAIRS>(p, splits, s);
     default: return launch_p5_act<CMB_ACT_NONE>(p, splits, s);
   }
 }

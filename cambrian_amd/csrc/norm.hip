@@ -814,6 +814,9 @@ int ln_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t row
   const int npos = grid_r * grid_r;
   const int64_t nwin = rows / npos;
   int64_t blocks = (nwin + 63) / 64;  // ~16 rows per wave: amortises the end-of-block atomics
+  // ... unless that leaves the chip mostly idle (the SVA query-side LayerNorms: 13 824 rows = 216 workgroups, 61 us = 0.16 of
+  // the HBM peak, profiles/r03_hbm_kernels_table.md): then ~4 rows per wave
+  if (blocks < 1024) blocks = (nwin + 15) / 16;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   const size_t smem = (size_t)4 * D * sizeof(float);

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("CAMBRIAN_AMD_LIB") or os.path.join(_HERE, "csrc", "li
 BF16, F32 = 0, 1
 F16 = 2   # output type of cmb_image_preprocess only
 FP8_E4M3 = 3   # operand type of cmb_gemm (OCP e4m3fn bytes from cmb_quantize_fp8_rows)
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU, ACT_SWIGLU_PAIRS = 0, 1, 2, 3, 4, 5
 ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf": ACT_GELU_ERF,
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}

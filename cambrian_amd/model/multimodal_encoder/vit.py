@@ -184,10 +184,13 @@ class ViTTrunk(nn.Module):
             buf(f"l{l}_proj_b", p[pre + "proj.bias"], torch.float32)
             F_ = cfg.mlp_dim
             if cfg.act == "swiglu":
+                # Dinov2SwiGLUFFN: x1 | x2 = weights_in(x).chunk(2); silu(x1) * x2.  Rows INTERLEAVED (2j = gate_j, 2j + 1 =
+                # up_j) so that the GEMM's epilogue forms the gated product itself (CMB_ACT_SWIGLU_PAIRS: the [tokens, 2 F]
+                # intermediate is never written; round 4: 40 act_mul launches of 68 us per 24-image step gone)
                 w1 = p[pre + "fc1.weight"].float()
                 b1 = p[pre + "fc1.bias"].float()
-                w1p = torch.cat([_pad_rows(w1[:F_], Fp), _pad_rows(w1[F_:], Fp)], 0)
-                b1p = torch.cat([_pad_rows(b1[:F_, None], Fp)[:, 0], _pad_rows(b1[F_:, None], Fp)[:, 0]], 0)
+                w1p = torch.stack([_pad_rows(w1[:F_], Fp), _pad_rows(w1[F_:], Fp)], 1).reshape(2 * Fp, -1)
+                b1p = torch.stack([_pad_rows(b1[:F_, None], Fp)[:, 0], _pad_rows(b1[F_:, None], Fp)[:, 0]], 1).reshape(2 * Fp)
             else:
                 w1p = _pad_rows(p[pre + "fc1.weight"].float(), Fp)
                 b1p = _pad_rows(p[pre + "fc1.bias"].float()[:, None], Fp)[:, 0]
@@ -229,7 +232,7 @@ class ViTTrunk(nn.Module):
         if cfg.pre_ln:
             x, _, _ = ops.k_layernorm_fwd(x, self.pre_ln_w, self.pre_ln_b, cfg.ln_eps, want_stats=False)
         act = {"quick_gelu": L.ACT_QUICK_GELU, "gelu": L.ACT_GELU_ERF, "gelu_tanh": L.ACT_GELU_TANH,
-               "swiglu": L.ACT_NONE}[cfg.act]
+               "swiglu": L.ACT_SWIGLU_PAIRS}[cfg.act]
         scale = 1.0 / math.sqrt(cfg.head_dim)
         for l in range(self.nl):
             g = lambda n: self._b(f"l{l}_{n}")  # noqa: E731
@@ -238,9 +241,7 @@ class ViTTrunk(nn.Module):
             a = vit_ops.k_vit_attn(qkv, B, N, cfg.num_heads, cfg.head_dim_pad, scale)
             x = ops.k_gemm(a, g("proj_w"), bias=g("proj_b"), colscale=g("ls1") if cfg.layerscale else None, residual=x)
             h, _, _ = ops.k_layernorm_fwd(x, g("ln2_w"), g("ln2_b"), cfg.ln_eps, want_stats=False)
-            f = ops.k_gemm(h, g("fc1_w"), bias=g("fc1_b"), act=act)
-            if cfg.act == "swiglu":
-                f = vit_ops.k_act_mul(f[:, : self.fpad], f[:, self.fpad:], L.ACT_SILU)
+            f = ops.k_gemm(h, g("fc1_w"), bias=g("fc1_b"), act=act)      # (swiglu: [tokens, F] = silu(gate) * up already)
             x = ops.k_gemm(f, g("fc2_w"), bias=g("fc2_b"), colscale=g("ls2") if cfg.layerscale else None, residual=x)
         if cfg.final_ln:
             x, _, _ = ops.k_layernorm_fwd(x, self.final_ln_w, self.final_ln_b, cfg.ln_eps, want_stats=False)

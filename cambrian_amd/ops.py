@@ -71,9 +71,10 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
         a_map = L.identity_map(a.stride(0))
     assert M is not None
     odt = out_dtype or (out.dtype if out is not None else dt)
+    n_out = N // 2 if act == L.ACT_SWIGLU_PAIRS else N   # gated epilogue: (gate, up) column pairs -> N / 2 outputs
     if out is None:
-        out = torch.empty((M, N), dtype=odt, device=a.device)
-        c_map = L.identity_map(N)
+        out = torch.empty((M, n_out), dtype=odt, device=a.device)
+        c_map = L.identity_map(n_out)
     elif c_map is None:
         if out.dim() != 2 or out.stride(1) != 1:
             raise L.CambrianAmdError("gemm out must be 2-D row-major unless c_map is given")
@@ -261,13 +262,15 @@ class gemm_census:
         GEMM_CENSUS = self.prev
         return False
 
-    def top(self, n: int = 8):
+    def top(self, n: int = 8, min_tiles: int = 257):
         """The n problems with the most FLOPs per step among those where both 256 x 256 kernels apply: whole tile
-        columns, K of at least two 64-deep tiles, no pre-activation copy, more than one round of tiles."""
+        columns, K of at least two 64-deep tiles, no pre-activation copy, at least ``min_tiles`` tiles (257 = more than one
+        round of the 256 CUs: where the library's own default is the 4-wave kernel; lower values also put single-round
+        problems — the 8-wave kernel's by default — to the test)."""
         rows = []
         for (M, N, K, act, pre), cnt in self.shapes.items():
-            tiles = ((M + 255) // 256) * (N // 256)
-            if pre or N % 256 or K < 128 or K % 64 or tiles <= 256:
+            tiles = ((M + 255) // 256) * ((N + 255) // 256)
+            if pre or N % 128 or K < 128 or K % 64 or tiles < min_tiles:
                 continue
             if L.load().cmb_gemm_tail_rows(M, N):
                 continue   # launched as 256-tile head + 128-tile tail (gemm.hip "Tail split"): the policy does not apply

@@ -47,7 +47,12 @@ enum { CMB_BF16 = 0, CMB_F32 = 1 };
  * A / B are uint8 [rows, K] produced by cmb_quantize_fp8_rows, C / residual / pre_out are bf16 (or fp32 C). */
 enum { CMB_FP8_E4M3 = 3 };
 enum { CMB_ACT_NONE = 0, CMB_ACT_GELU_ERF = 1, CMB_ACT_GELU_TANH = 2, CMB_ACT_QUICK_GELU = 3,
-       CMB_ACT_SILU = 4 };
+       CMB_ACT_SILU = 4,
+       /* cmb_gemm only: the gated activation of a packed (gate | up) projection whose weight rows are INTERLEAVED (row 2j =
+        * gate_j, row 2j + 1 = up_j): C[m, j] = silu(v[m, 2j]) * v[m, 2j + 1] with v = alpha * acc + bias — C has N / 2
+        * columns (HF Dinov2SwiGLUFFN reached from dino_encoder.py:159: weights_in + silu(x1) * x2 in one launch, the
+        * [M, N] intermediate never written).  N % 16 == 0; no colscale / residual / pre_out / split-K / fp32 C. */
+       CMB_ACT_SWIGLU_PAIRS = 5 };
 
 typedef struct cmb_rowmap {
   int64_t n1, n2;      /* n1 == 0: identity (offset = r * s2) */

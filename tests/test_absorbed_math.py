@@ -44,7 +44,7 @@ def test_absorbed_equals_direct(T, nsmall):
 
 
 def test_absorbed_tower_selection(monkeypatch):
-    """VisionCrossAttentionLayer._absorbed_tower: which configuration takes the absorbed path — bf16, 1024-wide features,
+    """VisionCrossAttentionLayer._absorbed_tower: which configuration takes the absorbed path — bf16 or fp32, 1024-wide features,
     exactly one windowed tower (up to 4 x 4) beside at most four one-key towers, fp8 projections off, switch on."""
     import cambrian_amd.model.vision_sampler as VS
     from cambrian_amd import ops
@@ -58,7 +58,8 @@ def test_absorbed_tower_selection(monkeypatch):
     monkeypatch.setattr(VS, "ABSORB_KV", True)
     assert layer(rel)._absorbed_tower(q16, feats(rel)) == 3                       # the release tower set
     assert layer([4, 1])._absorbed_tower(q16, feats([4, 1])) == 0
-    assert layer(rel)._absorbed_tower(q32, feats(rel)) == -1                      # fp32 parity path: per-token K|V
+    assert layer(rel)._absorbed_tower(q32, feats(rel)) == 3                       # fp32: the exact instantiation (round 4)
+    assert layer(rel)._absorbed_tower(q32.double(), feats(rel)) == -1             # any other dtype: per-token K|V
     assert layer([1, 1, 2, 4])._absorbed_tower(q16, feats([1, 1, 2, 4])) == -1    # two windowed towers
     assert layer([1, 1, 1, 1])._absorbed_tower(q16, feats([1, 1, 1, 1])) == -1    # none
     assert layer([1, 8])._absorbed_tower(q16, feats([1, 8])) == -1                # window larger than 4 x 4

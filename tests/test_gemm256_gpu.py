@@ -165,15 +165,15 @@ def test_gemm_p5_register_epilogue(dev, M, mode, tile):
 
 
 def test_default_dispatch_reports_its_kernel(dev):
-    """cmb_gemm_last_kernel: the default picks the 4-wave register-buffered kernel when N is a multiple of 256, K holds
-    two 64-deep tiles and there is more than one round of tiles per CU; the 8-wave kernel for a ragged tile column, K = 64
-    or a single round; the 128 tile for small problems; all agree on the result."""
+    """cmb_gemm_last_kernel: the default picks the 4-wave register-buffered kernel when N is a multiple of 128 (round 4: half
+    column tiles), K holds two 64-deep tiles and there are at least 64 tiles; the 8-wave kernel for a ragged half tile, K = 64
+    or fewer tiles; the 128 tile for small problems; all agree on the result."""
     ops, L = _ops()
     g = torch.Generator().manual_seed(77)
     dt = torch.bfloat16
     outs = {}
-    for (M, N, K), want in [((32768, 2048, 512), 2590), ((32768, 1152, 512), 256), ((32768, 2048, 64), 256), ((8192, 2048, 512), 256),
-                             ((64, 64, 64), 128)]:
+    for (M, N, K), want in [((32768, 2048, 512), 2590), ((32768, 1152, 512), 2590), ((32768, 1160, 512), 256), ((32768, 2048, 64), 256),
+                             ((8192, 2048, 512), 2590), ((1536, 2048, 512), 256), ((64, 64, 64), 128)]:
         a, w = torch.randn(M, K, generator=g).to(dev, dt), (torch.randn(N, K, generator=g) * 0.2).to(dev, dt)
         out = ops.k_gemm(a, w)
         assert L.load().cmb_gemm_last_kernel() == want, (M, N, K, L.load().cmb_gemm_last_kernel())
@@ -235,3 +235,80 @@ def test_tail_split_is_the_same_gemm(dev, M, N, K, mode):
     assert rel_err(out, ref) < tol and rel_err(whole, ref) < tol
     assert torch.equal(out[:m1], whole[:m1])              # the head rows: same 256-tile arithmetic, bit for bit
     assert rel_err(out[m1:], whole[m1:].float()) < (2e-5 if mode == "f32out" else 8e-3)
+
+
+@pytest.mark.parametrize("M,N,K,tile,dt,has_bias", [
+    (1000, 512, 256, 2590, torch.bfloat16, True), (1000, 512, 256, 2560, torch.bfloat16, True), (1000, 512, 256, 128, torch.bfloat16, True),
+    (17520 // 8, 8192, 1536, 0, torch.bfloat16, True), (777, 1024, 128, 2590, torch.bfloat16, False), (300, 96, 64, 128, torch.float32, True),
+    (513, 2048, 192, 2590, torch.bfloat16, True)])
+def test_gemm_swiglu_pairs_epilogue(dev, M, N, K, tile, dt, has_bias):
+    """CMB_ACT_SWIGLU_PAIRS (round 4): interleaved (gate_j, up_j) weight rows, C[m, j] = silu(v[m, 2j]) * v[m, 2j + 1] in the
+    GEMM's epilogue, C is N / 2 wide — HF Dinov2SwiGLUFFN's weights_in + silu(x1) * x2 in one launch; every kernel (4-wave,
+    8-wave, 128-tile; fp32 on the exact MFMA), ragged row counts, with and without bias; all three kernels agree bit for bit."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dt).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if has_bias else None
+    v = a.float() @ w.float().T + (b if has_bias else 0.0)
+    ref = torch.nn.functional.silu(v[:, 0::2]) * v[:, 1::2]
+    out = ops.k_gemm(a, w, bias=b, act=L.ACT_SWIGLU_PAIRS, tile=tile)
+    assert out.shape == (M, N // 2) and out.dtype == dt
+    assert rel_err(out, ref) < (2e-5 if dt == torch.float32 else 1e-2)
+    if dt == torch.bfloat16 and N % 256 == 0 and K >= 128:
+        outs = [ops.k_gemm(a, w, bias=b, act=L.ACT_SWIGLU_PAIRS, tile=t) for t in (2590, 2560, 128)]
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # what it replaces: the plain GEMM followed by the gated product on the packed halves
+    if dt == torch.bfloat16:
+        wp = torch.cat([w[0::2], w[1::2]], 0).contiguous()
+        bp = None if b is None else torch.cat([b[0::2], b[1::2]], 0).contiguous()
+        full = ops.k_gemm(a, wp, bias=bp, tile=tile)
+        from cambrian_amd.model.multimodal_encoder import vit_ops
+        two = vit_ops.k_act_mul(full[:, : N // 2], full[:, N // 2:], L.ACT_SILU)
+        assert rel_err(out, two.float()) < 1e-2      # (the unfused form rounds the [M, N] intermediate to bf16)
+
+
+def test_gemm_swiglu_pairs_rejects_other_epilogues(dev):
+    ops, L = _ops()
+    a = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(L.CambrianAmdError):
+        ops.k_gemm(a, w, act=L.ACT_SWIGLU_PAIRS, colscale=torch.ones(256, device=dev))
+    with pytest.raises(L.CambrianAmdError):
+        ops.k_gemm(a, w, act=L.ACT_SWIGLU_PAIRS, residual=torch.zeros(256, 128, dtype=torch.bfloat16, device=dev))
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(1000, 384, 256, "bias_gelu"), (2187, 1152, 512, "bias_cs_res"), (4096, 128, 1536, "plain"),
+                                         (700, 1408, 128, "bias"), (33000, 384, 1536, "bias_cs_res")])
+def test_p5_half_column_tiles(dev, M, N, K, mode):
+    """gemm_nt_p5_kernel on N % 256 == 128 (round 4: SigLIP's 1152-wide projections, ConvNeXt stage 1's 384-wide fc2): the last
+    column tile's upper waves skip the epilogue, nothing is written beyond column N (the output buffer is followed by a
+    sentinel), every epilogue form; equal to the 8-wave kernel bit for bit where their arithmetic is the same."""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    dt = torch.bfloat16
+    a = torch.randn(M, K, generator=g).to(dt).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(dev)
+    kw, ref = {}, a.float() @ w.float().T
+    if "bias" in mode:
+        b = torch.randn(N, generator=g).to(dev)
+        kw["bias"], ref = b, ref + b
+    if "gelu" in mode:
+        kw["act"], ref = L.ACT_GELU_ERF, F.gelu(ref)
+    if "cs" in mode:
+        cs = torch.randn(N, generator=g).to(dev)
+        kw["colscale"], ref = cs, ref * cs
+    if "res" in mode:
+        r = torch.randn(M, N, generator=g).to(dt).to(dev)
+        kw["residual"], ref = r, ref + r.float()
+    buf = torch.full((M * N + 4096,), 7.0, dtype=dt, device=dev)
+    out = buf[: M * N].view(M, N)
+    ops.k_gemm(a, w, out=out, tile=2590, **kw)
+    assert L.load().cmb_gemm_last_kernel() == 2590
+    assert rel_err(out, ref) < 1e-2
+    assert bool((buf[M * N:] == 7.0).all())
+    if "cs" not in mode:
+        assert torch.equal(out, ops.k_gemm(a, w, tile=2560, **kw))
+    # default dispatch takes the 4-wave kernel for such shapes now (when the grid is large enough), possibly as head + tail
+    out2 = ops.k_gemm(a, w, **kw)
+    assert rel_err(out2, ref) < 1e-2
