@@ -166,14 +166,14 @@ def test_gemm_p5_register_epilogue(dev, M, mode, tile):
 
 def test_default_dispatch_reports_its_kernel(dev):
     """cmb_gemm_last_kernel: the default picks the 4-wave register-buffered kernel when N is a multiple of 128 (round 4: half
-    column tiles), K holds two 64-deep tiles and there are at least 64 tiles; the 8-wave kernel for a ragged half tile, K = 64
-    or fewer tiles; the 128 tile for small problems; all agree on the result."""
+    column tiles), K holds two 64-deep tiles and the cost model prefers 256 x 256 tiles at all; the 8-wave kernel for a ragged half tile or
+    K = 64; the 128 tile for small problems; all agree on the result."""
     ops, L = _ops()
     g = torch.Generator().manual_seed(77)
     dt = torch.bfloat16
     outs = {}
     for (M, N, K), want in [((32768, 2048, 512), 2590), ((32768, 1152, 512), 2590), ((32768, 1160, 512), 256), ((32768, 2048, 64), 256),
-                             ((8192, 2048, 512), 2590), ((1536, 2048, 512), 256), ((64, 64, 64), 128)]:
+                             ((8192, 2048, 512), 2590), ((1536, 2048, 512), 128), ((64, 64, 64), 128)]:
         a, w = torch.randn(M, K, generator=g).to(dev, dt), (torch.randn(N, K, generator=g) * 0.2).to(dev, dt)
         out = ops.k_gemm(a, w)
         assert L.load().cmb_gemm_last_kernel() == want, (M, N, K, L.load().cmb_gemm_last_kernel())
