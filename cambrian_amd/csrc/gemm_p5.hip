@@ -43,6 +43,31 @@ __device__ __forceinline__ void p4_colvec(const float* base, bool upper, float (
   }
 }
 
+// Four consecutive 16-float groups (one column half of a wave: 64 columns) with ONE wait: four back-to-back scalar loads
+// expose one trip to the scalar cache / L2 instead of four (round 4: a bias cost the kernel ~7 us per item — 24 KB of bias
+// across 256 CUs does not live in the 16 KB scalar caches, and every p4_colvec waited for its own load: eight exposed round
+// trips per item; DINOv2 proj 78.9 -> 92.9 us with a bias, profiles/r04_lab.md).
+__device__ __forceinline__ void p4_colvec4(const float* base, bool upper, float (&v)[4][8]) {
+  f32x16s_t o0, o1, o2, o3;
+  asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\t"
+               "s_load_dwordx16 %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(o0), "=&s"(o1), "=&s"(o2), "=&s"(o3)
+               : "s"(base)
+               : "memory");
+  auto pick = [&](const f32x16s_t& o, float (&d)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float lo = o[e], hi = o[8 + e];
+      asm volatile("" : "+s"(lo), "+s"(hi));
+      d[e] = upper ? hi : lo;
+    }
+  };
+  pick(o0, v[0]);
+  pick(o1, v[1]);
+  pick(o2, v[2]);
+  pick(o3, v[3]);
+}
+
 __device__ __forceinline__ const char* p4_uniform_ptr(const char* q) {
   const uint64_t v = (uint64_t)q;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);

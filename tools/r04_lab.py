@@ -217,3 +217,32 @@ if "lnmulti" in only:
         emit(kernel="layernorm_bwd_multi", shape=f"{rows}x{D} x{Ln} layers", chunk=chunk, us=round(us, 1),
              tbps=round(rows * D * (2 * Ln + 2 * nl + 8 * nl - 4) / us / 1e6, 2))
     L.knob_set(L.KNOB_LN_MULTI_CHUNK, 7)
+
+if "epiforms" in only:
+    # what each epilogue ingredient costs the 4-wave kernel on short-K and long-K shapes of the path; the forms are timed
+    # round-robin (7 rounds of 10 launches each, minimum per form): one-after-the-other timing of 80 us kernels is dominated by
+    # clock / cache state drift
+    for name, M, N, K in (("DINOv2 proj", B * 730, 1536, 1536), ("DINOv2 fc2", B * 730, 1536, 4096), ("ConvNeXt s3 fc1", B * 4096, 6144, 1536),
+                          ("ConvNeXt s3 fc2", B * 4096, 1536, 6144), ("CLIP proj", B * 577, 1024, 1024)):
+        a, w = rn(M, K), rn(N, K, scale=K ** -0.5)
+        bias, cs, res = rn(N, dtype=f32), rn(N, dtype=f32), rn(M, N)
+        out = torch.empty(M, N, device=dev, dtype=bf)
+        modes = ("", "b", "bc", "br", "bcr", "r", "bg")
+        best = {m: 1e30 for m in modes}
+        for rep in range(7):
+            for mode in modes:
+                kw = {}
+                if "b" in mode:
+                    kw["bias"] = bias
+                if "c" in mode:
+                    kw["colscale"] = cs
+                if "r" in mode:
+                    kw["residual"] = res
+                if "g" in mode:
+                    kw["act"] = L.ACT_GELU_ERF
+                us = timeit(lambda: ops.k_gemm(a, w, out=out, tile=2590, **kw), iters=10)
+                best[mode] = min(best[mode], us)
+        for mode in modes:
+            emit(kernel="gemm_p5 epilogue forms", shape=f"{name} {M}x{N}x{K}", mode=mode or "plain", us=round(best[mode], 1),
+                 tflops=round(2.0 * M * N * K / best[mode] / 1e6, 1))
+        del a, w, out, res
