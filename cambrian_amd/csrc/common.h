@@ -112,8 +112,14 @@ __device__ __forceinline__ float wave_max(float v) {
 //               re-evaluates the same coefficients in numpy against math.erf).
 __device__ __forceinline__ float cmb_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float cmb_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float cmb_sigmoid(float x) { return cmb_rcp(1.0f + cmb_exp(-x)); }
-__device__ __forceinline__ float cmb_tanh(float u) { return 1.0f - 2.0f * cmb_rcp(1.0f + cmb_exp(2.0f * u)); }
+__device__ __forceinline__ float cmb_sigmoid(float x) {
+#pragma clang fp contract(off)
+  return cmb_rcp(1.0f + cmb_exp(-x));
+}
+__device__ __forceinline__ float cmb_tanh(float u) {
+#pragma clang fp contract(off)
+  return 1.0f - 2.0f * cmb_rcp(1.0f + cmb_exp(2.0f * u));
+}
 __device__ __forceinline__ float cmb_erf(float a) {
   const float t = fabsf(a), s = a * a;
   float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
@@ -175,7 +181,11 @@ __device__ __forceinline__ void cmb_gelu_erf_bf16_pair(float& a, float& b) {
   b = o[1];
 }
 
+// (no floating-point contraction in the activation helpers and the GEMM epilogues: which a * b + c pairs the compiler fuses
+// depends on the surrounding code, and the GEMM kernels must agree bit for bit — a problem's rows may be split between two of
+// them, and the batch an image arrives in decides which kernel its rows take)
 __device__ __forceinline__ float act_apply(int act, float x) {
+#pragma clang fp contract(off)
   switch (act) {
     case CMB_ACT_GELU_ERF: return 0.5f * x * (1.0f + cmb_erf(x * 0.70710678118654752440f));
     case CMB_ACT_GELU_TANH: {
@@ -188,6 +198,7 @@ __device__ __forceinline__ float act_apply(int act, float x) {
   }
 }
 __device__ __forceinline__ float act_grad(int act, float x) {
+#pragma clang fp contract(off)
   switch (act) {
     case CMB_ACT_GELU_ERF: {
       const float cdf = 0.5f * (1.0f + cmb_erf(x * 0.70710678118654752440f));

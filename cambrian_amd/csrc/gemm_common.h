@@ -91,6 +91,7 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 // switch in here is re-evaluated for each of the 8 elements: ~10 scalar compare/branch instructions per element).
 template <typename T, int ACT>
 __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int gm, int gn, float (&v)[8]) {
+#pragma clang fp contract(off)   // every fused multiply-add below is written as one: the same roundings as gemm_p5_epilogue.inc
   if (p.slabs) {  // split-K partial: raw fp32 slab, reduced by splitk_reduce_kernel
     Vec8<float>::store(p.slabs + ((int64_t)kz * p.slab_rows + gm) * p.N + gn, v);
     return;
@@ -102,13 +103,14 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= sa * sb[e];
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
   if (p.bias) {
     float bb[8];
     load8f(p.bias + gn, bb);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bb[e];
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], p.alpha, bb[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
   }
   if constexpr (ACT == CMB_ACT_SWIGLU_PAIRS) {
     // (gate, up) column pairs -> 4 outputs at columns gn / 2 .. gn / 2 + 3 of an N / 2 wide C; nothing else applies (dispatch)

@@ -21,7 +21,7 @@ from cambrian_amd import lib as L  # noqa: E402
 from cambrian_amd import ops  # noqa: E402
 from cambrian_amd.model.multimodal_encoder import vit_ops as V  # noqa: E402
 
-B = 16
+B = int(os.environ.get("CAMBRIAN_HBM_BENCH_IMAGES", "24"))   # images per GPU (24 = the driver's batch since round 3; r03 tables: 16)
 dev = torch.device("cuda", 0)
 bf, f32 = torch.bfloat16, torch.float32
 
@@ -42,7 +42,7 @@ def cases():
         def mk(rows=rows, D=D):
             x, g, b = rn(rows, D), rn(D, dtype=f32), rn(D, dtype=f32)
             return lambda: ops.k_layernorm_fwd(x, g, b, 1e-6, want_stats=False)
-        add(f"layernorm_fwd [{tag}]", "layernorm_fwd_kernel", f"{rows}x{D}", rows * D * 2 * 2, mk)
+        add(f"layernorm_fwd [{tag}]", "layernorm_fwd_lds_kernel", f"{rows}x{D}", rows * D * 2 * 2, mk)
     # ---- SVA shared-statistics normalisation (x + pos -> xhat, statistics kept): the ConvNeXt tower's 9216 tokens / image
     rows, D = B * 9216, 1024
 
@@ -59,6 +59,21 @@ def cases():
     # reads dn, x (bf16), fp32 accumulator read + write, statistics
     add("layernorm_bwd [SVA, fp32 accumulate, ConvNeXt tower]", "layernorm_bwd_kernel<.., true>", f"{rows}x{D}",
         rows * D * (2 + 2 + 4 + 4) + rows * 8, mk_svanb)
+
+    def mk_multi(rows=rows, D=D):
+        x = rn(rows, D)
+        items, dadd = [], []
+        for l in range(13):
+            pos = rn(16, D, dtype=f32)
+            _, mean, rstd = ops.k_layernorm_fwd(x, None, None, 1e-5, add=pos, side=96, grid_r=4)
+            items.append((rn(rows, D), mean, rstd, pos, l))
+            dadd.append(torch.zeros(16, D, device=dev, dtype=f32))
+        acc = torch.empty(rows, D, device=dev, dtype=f32)
+        return lambda: ops.k_layernorm_bwd_multi(x, items, 96, 4, acc, False, dadd)
+    # 13 layers in launches of 4 + 4 + 4 + 1: x read per launch (4 x 2), every gradient once (13 x 2), the fp32 sum written by
+    # each launch and re-read by the next three (4 x 4 + 3 x 4)
+    add("layernorm_bwd_multi [the 13 SVA layers of the ConvNeXt tower, one deferred pass]", "layernorm_bwd_multi_kernel",
+        f"{rows}x{D} x 13 layers", rows * D * (4 * 2 + 13 * 2 + 4 * 4 + 3 * 4), mk_multi)
 
     def mk_lnb(D=D):
         r2 = B * 576
@@ -150,19 +165,29 @@ def cases():
         return lambda: L.check(lib.cmb_rmsnorm_bwd_add(L.BF16, dy.data_ptr(), x.data_ptr(), gs.data_ptr(), rows, D, w.data_ptr(),
                                                        rstd.data_ptr(), dx.data_ptr(), L.stream_ptr(dev)), "rmsnorm_bwd_add")
     add("rmsnorm_bwd_add", "rmsnorm_bwd_add_kernel", f"{rows}x{D}", rows * D * 2 * 4, mk_rmsb)
-    # ---- ConvNeXt multi-stage resample: stage maps -> 96 x 96 grid of the 5760-channel buffer (one launch per stage)
+    # ---- ConvNeXt multi-stage resample: stage maps -> 96 x 96 grid of the 5760-channel buffer (one launch per stage).
+    # Algorithmic bytes = the source pixels the bilinear taps actually TOUCH (a 256 -> 96 downscale reads 2 of every 2.67
+    # rows and columns: 56 % of the map; VERDICT r3 #8: charging the whole map gave an impossible 8.0 TB/s) + the output
+    def touched(side, out=96):
+        import numpy as np
+        o = np.arange(out)
+        src = np.clip((o + 0.5) * (side / out) - 0.5, 0, side - 1)
+        i0 = np.floor(src).astype(int)
+        return len(set(i0.tolist()) | set(np.minimum(i0 + 1, side - 1).tolist()))
     for side, C, tag in ((256, 384, "stage 1"), (64, 1536, "stage 3")):
         def mk(side=side, C=C):
             x = rn(B, side * side, C)
             o = torch.empty(B, 9216, 5760, device=dev, dtype=bf)
             return lambda: V.k_resample(x, side, side, o, 96, 96, 0)
-        add(f"resample_bilinear [{tag} -> 96x96]", "resample_kernel", f"{B}x{side}^2x{C}", B * (side * side + 9216) * C * 2, mk)
+        u = touched(side)
+        add(f"resample_bilinear [{tag} -> 96x96]", "resample_kernel", f"{B}x{side}^2x{C} ({u}^2 source pixels touched)",
+            B * (u * u + 9216) * C * 2, mk)
     # ---- depthwise 7x7 (NHWC), stage 3 and stage 1
     for side, C, tag in ((64, 1536, "stage 3"), (256, 384, "stage 1")):
         def mk(side=side, C=C):
             x, w, b = rn(B, side, side, C), rn(49, C, dtype=f32), rn(C, dtype=f32)
             return lambda: V.k_dwconv7x7(x, w, b)
-        add(f"dwconv7x7 [{tag}] (VALU-bound: 98 FLOP / element)", "dwconv7x7_lds_kernel", f"{B}x{side}^2x{C}",
+        add(f"dwconv7x7 [{tag}] (VALU-bound: 98 FLOP / element)", "dwconv7x7_col_kernel", f"{B}x{side}^2x{C}",
             B * side * side * C * 2 * 2, mk)
     # ---- embedding splice, column sum (bias gradient), token mean, row gather, transpose, cast
     S, H, V_ = 2048, 4096, 128256
