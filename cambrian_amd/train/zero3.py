@@ -88,7 +88,20 @@ class Zero3Unit:
             self.log.append((what, self.index))
 
     # ---- forward -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _recomputing() -> bool:
+        """True while autograd is executing a backward pass: a forward of the module seen then is the activation
+        recompute of a non-reentrant ``torch.utils.checkpoint`` region around it (cambrian_llama.py wraps every decoder
+        layer in one when ``gradient_checkpointing`` is set; the reference: train_fsdp.py:1299-1304 under FSDP)."""
+        return torch._C._current_graph_task_id() != -1
+
     def _pre_forward(self, module, args) -> None:
+        if self._recomputing():
+            # the recompute runs INSIDE this unit's backward: the parameters must be (and stay) resident, the pending
+            # gradient count of the backward is kept.  Normally the output gradient hook has already started the
+            # backward; start it here if the recompute is the first thing autograd does with the unit.
+            self._begin_backward()
+            return
         self._in_backward = False      # a new forward: the next output gradient starts a new backward of this unit
         self.gather()
         self._start_neighbour(+1)
@@ -113,12 +126,18 @@ class Zero3Unit:
         return []
 
     def _post_forward(self, module, args, out):
+        if self._recomputing():
+            return                     # the backward that asked for the recompute still needs the parameters
         self.release()
         for t in self._tensors(out):
             if t.requires_grad:
                 t.register_hook(self._grad_of_output)
 
     def _grad_of_output(self, grad):
+        self._begin_backward()
+        return grad
+
+    def _begin_backward(self) -> None:
         if not self._in_backward:
             self._in_backward = True
             prev = Zero3Unit._bw_prev
@@ -126,7 +145,6 @@ class Zero3Unit:
                 prev.release()
             Zero3Unit._bw_prev = self
             self._pre_backward()
-        return grad
 
     # ---- residency -----------------------------------------------------------------------------------------------
     def _issue(self, async_op: bool) -> None:

@@ -211,3 +211,37 @@ def test_zero3_backward_starts_from_any_output():
     (ref(x).pow(2).mean() + (ref(x) * 2.0).mean()).backward()
     want = torch.cat([ref.weight.grad.reshape(-1), ref.bias.grad.reshape(-1)])
     assert torch.allclose(u.shard.grad[: want.numel()], want, atol=1e-6)
+
+
+def test_zero3_under_activation_recompute():
+    """Every unit inside a non-reentrant checkpoint region (the finetune stage's decoder layers): the recompute's
+    forward runs inside the unit's backward and must neither release the parameters nor restart the gradient count."""
+    from torch.utils.checkpoint import checkpoint
+    from cambrian_amd.train.zero3 import zero3_finalize, zero3_parameters, zero3_wrap
+
+    def run(blocks, x):
+        for b in blocks:
+            x = checkpoint(b, x, use_reentrant=False)
+        return x.pow(2).mean()
+
+    blocks = _blocks()
+    for p in blocks[1].parameters():
+        p.requires_grad_(False)
+    units = zero3_wrap(blocks)
+    log = []
+    for u in units:
+        u.log = log
+    opt = torch.optim.AdamW(zero3_parameters(units), lr=1e-2, weight_decay=0.1)
+    for step in range(2):
+        x = _data(1, step)[0].requires_grad_(True)
+        run(blocks, x).backward()
+        zero3_finalize(units)
+        assert all(not u.resident for u in units)
+        opt.step()
+        opt.zero_grad()
+    # one gather per unit per pass, recompute included: forward 3 + backward 3 per step (prefetches count as gathers)
+    assert sum(1 for w, _ in log if w in ("gather", "prefetch")) == 12
+    want = _reference(1, 2)
+    for u, w in zip(units, want):
+        for a, b in zip(u.full_state(), w):
+            assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)

@@ -16,11 +16,12 @@ dev = torch.device("cuda:0")
 a = torch.randn(M, K, device=dev).to(torch.bfloat16)
 w = torch.randn(N, K, device=dev).to(torch.bfloat16)
 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+bias = torch.randn(N, device=dev) if act else None   # (an activation GEMM of the path always carries its bias)
 def run():
     if tile == "blas":
         torch.matmul(a, w.T, out=out)
     else:
-        ops.k_gemm(a, w, out=out, tile=tile, act=act)
+        ops.k_gemm(a, w, out=out, tile=tile, act=act, bias=bias)
 
 
 for _ in range(iters):
