@@ -805,8 +805,8 @@ def main():
                     "flop_model": "12.0 TFLOP per image: towers 9.169 forward (frozen) + SVA side 0.940 x 3 (SURVEY.md §8d) — the "
                                   "REFERENCE algorithm's count, whatever this build executes",
                     "absorbed_kv": bool(ABSORB_KV_ON),
-                    "executed_note": ("with the windowed tower's K / V projections absorbed into the query side (DESIGN.md §4 "
-                                      "'Absorbed K/V') the SVA side executes ~1.4 of its 2.8 TFLOP per image; the fraction above "
+                    "executed_note": ("with the windowed tower's K / V projections absorbed into the query side (DESIGN.md "
+                                      "§4.5) the SVA side executes ~1.4 of its 2.8 TFLOP per image; the fraction above "
                                       "stays on the reference's 12.0") if ABSORB_KV_ON else None}
             if prof_all:
                 fall, msall, nall = agg(prof_all, lambda x: x[3] == torch.bfloat16)

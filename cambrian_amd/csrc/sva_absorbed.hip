@@ -1,5 +1,5 @@
 // sva_absorbed.hip — SVA cross-attention core with the WINDOWED tower's K / V projections absorbed into the query side
-// (forward + backward, bf16, gfx950).  Round 3; DESIGN.md §4 "Absorbed K/V".
+// (forward + backward, bf16, gfx950).  Round 3; DESIGN.md §4.5.
 //
 // Reference semantics: MultiKVCrossAttention.forward, vision_sampler.py:187-230 — for every query one softmax over the
 // keys of all towers (s_i x s_i window of tower i under the query's cell), 16 heads x 64.  For a tower with an s x s

@@ -923,7 +923,7 @@ def sva_attention(q, kvs: Sequence[torch.Tensor], masks, r_list, B, qside, heads
 
 
 # ================================================================================================
-# absorbed K / V projections of the windowed tower (csrc/sva_absorbed.hip; DESIGN.md §4 "Absorbed K/V")
+# absorbed K / V projections of the windowed tower (csrc/sva_absorbed.hip)
 # ================================================================================================
 def k_gemm_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch: int, M: int, N: int, K: int, lda: int,
                    ldb: int, ldc: int, a_bs: int, b_bs: int, c_bs: int) -> torch.Tensor:
