@@ -140,45 +140,74 @@ __device__ __forceinline__ float cmb_erf(float a) {
   return t > 0.927734375f ? big : small;
 }
 
-// The bf16 GEMM epilogues' exact-erf GELU (the activation runs with the matrix pipe idle and the result is rounded to bf16; the
+// The bf16 GEMM epilogues' erf GELU (the activation runs with the matrix pipe idle and the result is rounded to bf16; the
 // fp32 kernels and the stand-alone activation kernels keep cmb_erf):
-//     GELU(x) = relu(x) - t * Phi(-t),  t = min(|x|, 16),  Phi(-t) = 2^P(t)
-// with P the degree-7 minimax fit of log2 Phi(-t) on [0, 6] (monotone decreasing to P(16) = -222, so the clamp only keeps
-// infinities finite).  |error| <= 5.1e-7 absolute, <= 4e-6 relative wherever |GELU| > 1e-3 (tests/test_act_math.py
-// re-evaluates these coefficients in numpy).  Round 4: ONE quarter-rate instruction (v_exp_f32) and 7 fma + min + max + fma per
-// element; rounds 2-3 used Abramowitz-Stegun 7.1.26 (v_rcp_f32 AND v_exp_f32, 5 fma + 5 other operations): the epilogue of
-// the 4-wave GEMM pays every VALU cycle in full, ConvNeXt fc1 + GELU 989 -> 1060 TFLOP/s (profiles/r04_lab.md).  Every
-// operation is an explicit fma / min / max (no contraction left to the compiler), so all GEMM kernels agree bit for bit.
+//     GELU(x) = relu(x) - t * Phi(-t),  t = min(|x|, 7),  Phi(-t) = 2^P(t)
+// with P a degree-5 weighted minimax fit of log2 Phi(-t) on [0, 7] (monotone decreasing to P(7) = -39.9: beyond the clamp the
+// correction term is 7e-12).  |error| <= 6.4e-6 absolute (2e-6 relative at x = 3), <= 4e-5 relative wherever |GELU| > 1e-3 —
+// 50 x below half a bf16 ulp (tests/test_act_math.py re-evaluates these coefficients in numpy).  ONE transcendental
+// (v_exp_f32) and 5 fma + min + max + fma per element; the first round-4 form had degree 7 (1e-5 relative: more than a bf16
+// result can show), rounds 2-3 used Abramowitz-Stegun 7.1.26 (v_rcp_f32 AND v_exp_f32, 5 fma + 5 other operations): the
+// epilogue of the 4-wave GEMM is issue-bound at one wave per SIMD, every instruction less is ~5.5 cycles per element pair
+// (profiles/r04_lab.md).  Every operation is an explicit fma / min / max (no contraction left to the compiler), so all GEMM
+// kernels agree bit for bit.
 __device__ __forceinline__ float cmb_gelu_erf_bf16(float x) {
-  const float t = fminf(fabsf(x), 16.0f);
-  float p = -1.6755886917962926e-06f;
-  p = fmaf(p, t, 5.900045289308764e-05f);
-  p = fmaf(p, t, -0.0009141339105553925f);
-  p = fmaf(p, t, 0.008457586169242859f);
-  p = fmaf(p, t, -0.05388267710804939f);
-  p = fmaf(p, t, -0.45851942896842957f);
-  p = fmaf(p, t, -1.151236891746521f);
-  p = fmaf(p, t, -0.9999958872795105f);
+  const float t = fminf(fabsf(x), 7.0f);
+  float p = -0.0003763301356229931f;
+  p = fmaf(p, t, 0.0063428147695958614f);
+  p = fmaf(p, t, -0.0498826801776886f);
+  p = fmaf(p, t, -0.4620113670825958f);
+  p = fmaf(p, t, -1.1501027345657349f);
+  p = fmaf(p, t, -1.0000579357147217f);
   return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
-// the same, two elements at a time on 2-vectors (identical results): hipcc keeps the scalar form as seven v_fmaak_f32
-// (literal constants) per element; on vector operands the Horner steps become v_pk_fma_f32 — half the issue slots
+// the same, two elements at a time on 2-vectors (identical results): hipcc keeps the scalar form as v_fmaak_f32 (literal
+// constants) per element; on vector operands the Horner steps become v_pk_fma_f32 — half the instructions, which is what
+// counts: one wave per SIMD issues an instruction every ~5.5 cycles whatever it is (profiles/r04_lab.md)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cmb_gelu_erf_bf16_pair(float& a, float& b) {
-  const f32x2_t t = {fminf(fabsf(a), 16.0f), fminf(fabsf(b), 16.0f)};
-  f32x2_t p = {-1.6755886917962926e-06f, -1.6755886917962926e-06f};
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){5.900045289308764e-05f, 5.900045289308764e-05f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.0009141339105553925f, -0.0009141339105553925f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.008457586169242859f, 0.008457586169242859f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.05388267710804939f, -0.05388267710804939f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.45851942896842957f, -0.45851942896842957f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-1.151236891746521f, -1.151236891746521f});
-  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.9999958872795105f, -0.9999958872795105f});
+  const f32x2_t t = {fminf(fabsf(a), 7.0f), fminf(fabsf(b), 7.0f)};
+  f32x2_t p = {-0.0003763301356229931f, -0.0003763301356229931f};
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){0.0063428147695958614f, 0.0063428147695958614f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.0498826801776886f, -0.0498826801776886f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.4620113670825958f, -0.4620113670825958f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-1.1501027345657349f, -1.1501027345657349f});
+  p = __builtin_elementwise_fma(p, t, (f32x2_t){-1.0000579357147217f, -1.0000579357147217f});
   const f32x2_t h = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
   const f32x2_t r = {fmaxf(a, 0.0f), fmaxf(b, 0.0f)};
   const f32x2_t o = __builtin_elementwise_fma(-t, h, r);
   a = o[0];
   b = o[1];
+}
+
+// eight elements at a time, the four pairs' Horner chains INTERLEAVED step by step: a dependent v_pk_fma_f32 right behind
+// its producer costs a wait state (hipcc puts an s_nop between them), and with one wave per SIMD nothing else fills it —
+// the pair-by-pair order above ran one s_nop per multiply-add (same results, operation for operation)
+__device__ __forceinline__ void cmb_gelu_erf_bf16_x8(float (&v)[8]) {
+  f32x2_t t[4], p[4], r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    t[k] = (f32x2_t){fminf(fabsf(v[2 * k]), 7.0f), fminf(fabsf(v[2 * k + 1]), 7.0f)};
+    r[k] = (f32x2_t){fmaxf(v[2 * k], 0.0f), fmaxf(v[2 * k + 1], 0.0f)};
+    p[k] = (f32x2_t){-0.0003763301356229931f, -0.0003763301356229931f};
+  }
+#define CMB_GELU_STEP(c)                                                              \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) p[k] = __builtin_elementwise_fma(p[k], t[k], (f32x2_t){c, c});
+  CMB_GELU_STEP(0.0063428147695958614f)
+  CMB_GELU_STEP(-0.0498826801776886f)
+  CMB_GELU_STEP(-0.4620113670825958f)
+  CMB_GELU_STEP(-1.1501027345657349f)
+  CMB_GELU_STEP(-1.0000579357147217f)
+#undef CMB_GELU_STEP
+  f32x2_t h[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) h[k] = (f32x2_t){__builtin_amdgcn_exp2f(p[k][0]), __builtin_amdgcn_exp2f(p[k][1])};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2_t o = __builtin_elementwise_fma(-t[k], h[k], r[k]);
+    v[2 * k] = o[0];
+    v[2 * k + 1] = o[1];
+  }
 }
 
 // (no floating-point contraction in the activation helpers and the GEMM epilogues: which a * b + c pairs the compiler fuses

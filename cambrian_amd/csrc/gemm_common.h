@@ -124,8 +124,7 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
   }
   if (p.P) Vec8<T>::store(reinterpret_cast<T*>(p.P) + row_off(p.p_map, (uint32_t)gm) + gn, v);
   if constexpr (ACT == CMB_ACT_GELU_ERF && std::is_same<T, bf16_t>::value) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) cmb_gelu_erf_bf16_pair(v[e], v[e + 1]);  // bf16 operands / results: common.h
+    cmb_gelu_erf_bf16_x8(v);  // bf16 operands / results: common.h (the four pairs' chains interleaved)
   } else if constexpr (ACT != CMB_ACT_NONE) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_apply(ACT, v[e]);

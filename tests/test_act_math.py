@@ -48,8 +48,9 @@ def test_cmb_erf_polynomials_within_one_ulp():
 
 
 def test_cmb_gelu_erf_bf16_within_bf16_rounding():
-    """The bf16 GEMM epilogues' GELU (common.h::cmb_gelu_erf_bf16: relu(x) - t 2^P(t), t = min(|x|, 16)), coefficients parsed from the
-    header and evaluated in float32: absolute error <= 6e-7, relative error <= 1e-5 wherever |GELU| > 1e-3, against the
+    """The bf16 GEMM epilogues' GELU (common.h::cmb_gelu_erf_bf16: relu(x) - t 2^P(t), t = min(|x|, 7)), coefficients parsed from the
+    header and evaluated in float32: absolute error <= 8e-6, relative error <= 5e-5 wherever |GELU| > 1e-3 (half a bf16 ulp
+    is 2e-3), against the
     exact-erf GELU of the reference (nn.GELU(), vision_sampler.py:241); P stays decreasing up to the clamp, so large inputs
     cannot turn the 2^P term back on; infinities stay finite / signed as GELU's limits."""
     src = open(os.path.join(ROOT, "cambrian_amd", "csrc", "common.h")).read()
@@ -57,7 +58,7 @@ def test_cmb_gelu_erf_bf16_within_bf16_rounding():
     body = body[:body.index("return fmaf(-t")]
     clamp = float(re.search(r"fminf\(fabsf\(x\), (\d+\.\d+)f\)", body).group(1))
     nums = [float(x.rstrip("f")) for x in re.findall(r"-?\d\.\d+(?:e-\d+)?f", body.split("float p =")[1])]
-    assert len(nums) == 8 and clamp == 16.0
+    assert len(nums) == 6 and clamp == 7.0
     # the pair form the GEMM epilogue calls carries the same numbers
     pair = src[src.index("void cmb_gelu_erf_bf16_pair"):]
     pair = pair[:pair.index("const f32x2_t h =")]
@@ -73,8 +74,8 @@ def test_cmb_gelu_erf_bf16_within_bf16_rounding():
     got = (np.maximum(x, f(0)).astype(np.float64) - t.astype(np.float64) * h).astype(f).astype(np.float64)
     ref = np.array([0.5 * float(v) * (1.0 + math.erf(float(v) / math.sqrt(2.0))) for v in x])
     err = np.abs(got - ref)
-    assert err.max() < 6e-7, err.max()
-    assert (err / np.maximum(np.abs(ref), 1e-3)).max() < 1e-5
+    assert err.max() < 8e-6, err.max()
+    assert (err / np.maximum(np.abs(ref), 1e-3)).max() < 5e-5
     tt = np.linspace(0, clamp, 200001)
     P = np.polyval(nums, tt)
-    assert (np.diff(P) < 0).all() and P[-1] < -150
+    assert (np.diff(P) < 0).all() and P[-1] < -39 and clamp * 2.0 ** P[-1] < 1e-11
