@@ -32,6 +32,38 @@ namespace {
 // do not have to wait behind the tile's stores and LDS-DMA on vmcnt) -> this lane's 8: lanes 0-31 take floats 0..7,
 // lanes 32-63 floats 8..15 (the column halves of one 16-column group after the permlane32 swap).
 typedef float f32x16s_t __attribute__((ext_vector_type(16)));
+// The staged 64 rows x 128 bytes of a wave leave as 8 stores of 8 rows (a lane: 16 bytes of row 8 k + (lane >> 3)).
+// When every row of the wave's block is in range (wave-uniform `all`: every row tile but the last) the loop has no
+// per-store row test: four LDS reads in flight, then their four stores, twice — the guarded form (each read behind its own
+// compare / exec branch / s_waitcnt lgkmcnt(0), the row limit and eight precomputed row offsets reloaded from spilled
+// scalars) cost ~110 issue slots and eight exposed LDS round trips per flush, four flushes per item (round 4, found by
+// reading the assembly: profiles/r04_lab.md).  C is written once and read by a later kernel: streaming stores (+1.5 % on the
+// path's large shapes, +7 % on the GELU one, round 2).
+__device__ __forceinline__ void p4_flush8(const char* stage_r0, const char* stage_r1, bf16_t* cptr, int64_t step, bool all,
+                                          int rows_left) {
+  if (all) {
+    bf16_t* q = cptr;
+#pragma unroll
+    for (int kb = 0; kb < 8; kb += 4) {
+      bf16x8_t o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        o[k] = *reinterpret_cast<const bf16x8_t*>((((kb + k) & 1) ? stage_r1 : stage_r0) + (kb + k) * 1024);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_nontemporal_store(o[k], reinterpret_cast<bf16x8_t*>(q));
+        q += step;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bf16x8_t o8 = *reinterpret_cast<const bf16x8_t*>(((k & 1) ? stage_r1 : stage_r0) + k * 1024);
+      if (8 * k < rows_left) __builtin_nontemporal_store(o8, reinterpret_cast<bf16x8_t*>(cptr + (int64_t)k * step));
+    }
+  }
+}
+
 __device__ __forceinline__ void p4_colvec(const float* base, bool upper, float (&v)[8]) {
   f32x16s_t o;
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(o) : "s"(base) : "memory");
@@ -48,6 +80,32 @@ __device__ __forceinline__ void p4_colvec(const float* base, bool upper, float (
 // across 256 CUs does not live in the 16 KB scalar caches, and every p4_colvec waited for its own load: eight exposed round
 // trips per item; DINOv2 proj 78.9 -> 92.9 us with a bias, profiles/r04_lab.md).
 __device__ __forceinline__ void p4_colvec4(const float* base, bool upper, float (&v)[4][8]) {
+#ifndef CMB_P5_COLVEC_ONE_WAIT
+  // two batches of two groups: 32 scalar registers in flight instead of 64 — with 64 the allocator spilled most of the
+  // kernel's loop-invariant scalars to vector lanes around every half tile and reloaded them (v_readlane_b32) wherever the
+  // epilogue needed one: ~250 reloads per item, every one an issue slot of the single wave on its SIMD
+  auto pair = [&](int off, float (&d0)[8], float (&d1)[8]) {
+    f32x16s_t o0, o1;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(o0), "=&s"(o1)
+                 : "s"(base + off)
+                 : "memory");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float lo = o0[e], hi = o0[8 + e];
+      asm volatile("" : "+s"(lo), "+s"(hi));
+      d0[e] = upper ? hi : lo;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float lo = o1[e], hi = o1[8 + e];
+      asm volatile("" : "+s"(lo), "+s"(hi));
+      d1[e] = upper ? hi : lo;
+    }
+  };
+  pair(0, v[0], v[1]);
+  pair(32, v[2], v[3]);
+#else
   f32x16s_t o0, o1, o2, o3;
   asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\t"
                "s_load_dwordx16 %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
@@ -66,6 +124,7 @@ __device__ __forceinline__ void p4_colvec4(const float* base, bool upper, float 
   pick(o1, v[1]);
   pick(o2, v[2]);
   pick(o3, v[3]);
+#endif
 }
 
 __device__ __forceinline__ const char* p4_uniform_ptr(const char* q) {
