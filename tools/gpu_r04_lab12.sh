@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 lab run 12: the leaner GELU epilogue (degree-5 polynomial, the four pairs' chains interleaved, accumulator reads in
-# one block) against the previous library (built from HEAD~: cambrian_amd/csrc/libcambrian_amd_lab_prev.so), per shape and on
+# one block) against the previous library (a lab build or the parent commit: cambrian_amd/csrc/libcambrian_amd_lab_prev.so), per shape and on
 # the whole step
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
