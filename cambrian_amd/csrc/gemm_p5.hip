@@ -93,7 +93,7 @@ __device__ __forceinline__ void p4_colvec4(const float* base, bool upper, float 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float lo = o0[e], hi = o0[8 + e];
-      asm volatile("" : "+s"(lo), "+s"(hi));
+      asm volatile("" : "+s"(lo), "+s"(hi));   // keep two scalars: select-of-extract otherwise becomes a dynamic extract
       d0[e] = upper ? hi : lo;
     }
 #pragma unroll
