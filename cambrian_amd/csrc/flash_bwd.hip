@@ -518,18 +518,28 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
           const int qrow = qs * 32 + 8 * r4 + 4 * g;  // rows qrow .. qrow+3 <-> registers 4*r4 .. 4*r4+3
           const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(sLse + qrow);
           const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(sD + qrow);
+          // four independent elements per step (fma x 4, exp x 4, sub x 4), not element by element: a dependent
+          // instruction right behind its producer waits out the pipeline latency, and one wave per SIMD has nothing to fill it
+          float t4[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * r4 + e;
-            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -l4[e]));
-            if (edge) {
-              const int qidx = qt * 64 + qrow + e;
-              if (!(CAUSAL ? (ki <= qidx && (kvalid || ki == qidx)) : ki < p.kv_len)) pv = 0.f;
-            }
-            pr[r] = pv;
-            s[r] = pv * (dp[r] - d4[e]);  // dS
+          for (int e = 0; e < 4; ++e) t4[e] = __builtin_fmaf(s[4 * r4 + e], c2, -l4[e]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pr[4 * r4 + e] = __builtin_amdgcn_exp2f(t4[e]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[4 * r4 + e] = dp[4 * r4 + e] - d4[e];
+        }
+        // The mask as ONE wave-uniform block over the 16 probabilities: inside the element loop hipcc if-converted the
+        // test into a compare + select per element on EVERY tile (64 of the tile's ~680 vector / scalar instructions; one
+        // wave per SIMD pays each in full), while only the tiles on the diagonal (or holding padding) need it.
+        if (edge) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qidx = qt * 64 + qs * 32 + 8 * (r >> 2) + 4 * g + (r & 3);
+            if (!(CAUSAL ? (ki <= qidx && (kvalid || ki == qidx)) : ki < p.kv_len)) pr[r] = 0.f;
           }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = pr[r] * s[r];  // dS = P (dP - D)
 #pragma unroll
         for (int qb16 = 0; qb16 < 2; ++qb16) {
           const int o8 = 8 * qb16;
