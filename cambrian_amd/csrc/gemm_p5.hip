@@ -67,12 +67,10 @@ __device__ __forceinline__ void p4_flush8(const char* stage_r0, const char* stag
 __device__ __forceinline__ void p4_colvec(const float* base, bool upper, float (&v)[8]) {
   f32x16s_t o;
   asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(o) : "s"(base) : "memory");
+  uint32_t m = upper ? 0xffffffffu : 0u;   // lane-half select as a bit merge: v_mov + v_bfi_b32 per value (see p4_colvec4)
+  asm volatile("" : "+v"(m));
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float lo = o[e], hi = o[8 + e];
-    asm volatile("" : "+s"(lo), "+s"(hi));  // keep two scalars: select-of-extract otherwise becomes a dynamic extract
-    v[e] = upper ? hi : lo;
-  }
+  for (int e = 0; e < 8; ++e) v[e] = __uint_as_float((__float_as_uint(o[e]) & ~m) | (__float_as_uint(o[8 + e]) & m));
 }
 
 // Four consecutive 16-float groups (one column half of a wave: 64 columns) with ONE wait: four back-to-back scalar loads
@@ -90,17 +88,14 @@ __device__ __forceinline__ void p4_colvec4(const float* base, bool upper, float 
                  : "=&s"(o0), "=&s"(o1)
                  : "s"(base + off)
                  : "memory");
+    // lane-half select as a bit merge (v_bfi_b32: one scalar operand + a v_mov for the other = 2 vector instructions per
+    // value, exact); `upper ? hi : lo` was v_mov + v_mov + v_cndmask + an s_mov per value
+    uint32_t m = upper ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));   // opaque: hipcc otherwise sees through the mask and rebuilds the three-instruction select
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float lo = o0[e], hi = o0[8 + e];
-      asm volatile("" : "+s"(lo), "+s"(hi));   // keep two scalars: select-of-extract otherwise becomes a dynamic extract
-      d0[e] = upper ? hi : lo;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float lo = o1[e], hi = o1[8 + e];
-      asm volatile("" : "+s"(lo), "+s"(hi));
-      d1[e] = upper ? hi : lo;
+      d0[e] = __uint_as_float((__float_as_uint(o0[e]) & ~m) | (__float_as_uint(o0[8 + e]) & m));
+      d1[e] = __uint_as_float((__float_as_uint(o1[e]) & ~m) | (__float_as_uint(o1[8 + e]) & m));
     }
   };
   pair(0, v[0], v[1]);
