@@ -93,7 +93,8 @@ class Zero3Unit:
         """True while autograd is executing a backward pass: a forward of the module seen then is the activation
         recompute of a non-reentrant ``torch.utils.checkpoint`` region around it (cambrian_llama.py wraps every decoder
         layer in one when ``gradient_checkpointing`` is set; the reference: train_fsdp.py:1299-1304 under FSDP)."""
-        return torch._C._current_graph_task_id() != -1
+        probe = getattr(torch._C, "_current_graph_task_id", None)   # private; absent -> the recompute case is not recognised
+        return probe is not None and probe() != -1
 
     def _pre_forward(self, module, args) -> None:
         if self._recomputing():
