@@ -135,7 +135,11 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:   # CAMBRIAN_DIST_BACKEND=gloo: exercise the N > 1 control flow with several ranks on ONE GPU
             backend = os.environ.get("CAMBRIAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if backend == "nccl":
+            # bind the communicator to this rank's device at creation (eager init, no "device unknown" barrier warnings,
+            # no lazy communicator build inside the first timed collective)
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
