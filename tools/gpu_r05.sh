@@ -1,0 +1,48 @@
+#!/bin/bash
+# Round 5: ONE parametrised gpurun command file (no per-call scratch scripts).
+#   tools/gpu_r05.sh bench            the driver's command, line -> gpurun_out/r05/bench_<tag>.json
+#   tools/gpu_r05.sh prof [steps]     rocprofv3 --kernel-trace --stats of the driver's command -> kernel_stats.md + timeline.json
+#   tools/gpu_r05.sh tests [expr]     pytest -m gpu (optionally -k expr) + smoke
+#   tools/gpu_r05.sh lab <args...>    python tools/r05_lab.py <args...>
+#   tools/gpu_r05.sh py <file> ...    python <file> ...
+# several verbs in one call: separate with '--'  (e.g. `tools/gpu_r05.sh bench -- prof`)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/r05; mkdir -p $O
+TAG=${TAG:-$(date +%H%M%S)}
+run_verb() {
+  local verb=$1; shift
+  case "$verb" in
+    bench)
+      timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 "$@" > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+      echo "bench rc=$? $(wc -c < $O/bench_$TAG.json) bytes"; cp gpurun_out/bench_line_full.json $O/bench_full_$TAG.json 2>/dev/null
+      python - <<P
+import json
+d=json.loads(open("$O/bench_$TAG.json").read().strip().splitlines()[-1]); r=d.get("roofline",{})
+print("ms/step", round(d["ms_per_step"],1), "img/s", round(d["value"],3), "frac", r.get("frac"), "region", r.get("region_ms_per_step"), r.get("region_frac"), "own_gemm", r.get("all_own_gemm_frac"))
+P
+      ;;
+    prof)
+      local steps=${1:-20}
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --gpus 1 --steps $steps --warmup 5 --no-cpu-baseline --no-ab > "$GRAFT_REPO_ROOT/$O/profiled_run_$TAG.json" 2> "$GRAFT_REPO_ROOT/$O/profiled_run_$TAG.err" )
+      DB=$(find $O/prof -name "*.db" | head -1)
+      python tools/rocpd_summary.py $DB 70 > $O/kernel_stats_$TAG.md 2>&1
+      python tools/rocpd_timeline.py $DB > $O/timeline_$TAG.json 2> $O/timeline_$TAG.err
+      rm -rf $O/prof
+      head -14 $O/kernel_stats_$TAG.md | cut -c1-170; head -c 1500 $O/timeline_$TAG.json
+      ;;
+    tests)
+      if [ -n "$1" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$1" 2>&1 | tail -15
+      else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15; fi
+      python __graft_entry__.py smoke 2>&1 | tail -2
+      ;;
+    lab) timeout 1200 python tools/r05_lab.py "$@" 2>&1 | tail -60 ;;
+    py) timeout 1200 python "$@" 2>&1 | tail -60 ;;
+    *) echo "unknown verb $verb"; return 2 ;;
+  esac
+}
+args=()
+for a in "$@"; do
+  if [ "$a" == "--" ]; then run_verb "${args[@]}"; args=(); else args+=("$a"); fi
+done
+[ ${#args[@]} -gt 0 ] && run_verb "${args[@]}"
