@@ -509,13 +509,58 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
         return {"loss": loss, "logits": logits}
 
 
+# generate() keyword arguments that change nothing here: the K/V cache is always on, padding / bos ids are not needed by a
+# loop that returns only the new tokens, and the listed output switches are accepted at their "off" value only
+_GENERATE_ACCEPTED_NOOPS = {"use_cache": (True, None), "pad_token_id": None, "bos_token_id": None, "output_scores": (False, None),
+                            "return_dict_in_generate": (False, None), "output_attentions": (False, None),
+                            "output_hidden_states": (False, None), "num_return_sequences": (1, None),
+                            "repetition_penalty": (1.0, None), "length_penalty": (1.0, None), "early_stopping": (False, None),
+                            "stopping_criteria": (None,), "logits_processor": (None,), "streamer": (None,)}
+
+
+def filter_logits_top_k_top_p(logits: torch.Tensor, top_k=None, top_p=None) -> torch.Tensor:
+    """HF's TopKLogitsWarper then TopPLogitsWarper (the order GenerationMixin applies them in, after the temperature), on
+    fp32 logits [B, V]: tokens outside the k largest, then tokens outside the smallest set whose probability mass reaches
+    ``top_p`` (ascending sort, drop while the cumulative mass <= 1 - top_p, always keep the most probable), are set to -inf."""
+    if top_k is not None and int(top_k) > 0:
+        k = min(int(top_k), logits.shape[-1])
+        kth = torch.topk(logits, k, dim=-1).values[..., -1:]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    if top_p is not None and float(top_p) < 1.0:
+        if not 0.0 < float(top_p):
+            raise ValueError(f"`top_p` has to be a float > 0 and <= 1, but is {top_p}")
+        srt, idx = torch.sort(logits, descending=False, dim=-1)
+        cum = srt.softmax(-1).cumsum(-1)
+        drop = cum <= (1.0 - float(top_p))
+        drop[..., -1:] = False
+        logits = logits.masked_fill(torch.zeros_like(drop).scatter(-1, idx, drop), float("-inf"))
+    return logits
+
+
 def _generate(self, inputs=None, images=None, image_sizes=None, max_new_tokens: int = 16, do_sample: bool = False,
-              temperature: float = 1.0, eos_token_id=None, attention_mask=None, position_ids=None, **_unused):
+              temperature: float = 1.0, eos_token_id=None, attention_mask=None, position_ids=None, top_p=None, top_k=None,
+              num_beams: int = 1, **kwargs):
     """cambrian_llama.py:437-483: ``generate(input_ids, images=, image_sizes=)`` of the eval harness
-    (eval/eval/*/…_eval.py).  Prefill = the eval branch of prepare_inputs_labels_for_multimodal + the decoder with the
-    per-sample in-LLM SVA hook, K/V of every layer kept; decode steps = one token against the cache, no hook
-    (cambrian_llama.py:174).  Greedy or temperature sampling; returns the NEW token ids [B, <= max_new_tokens]
-    (like HF generate() called with inputs_embeds).  The reference inherits the loop from HF GenerationMixin."""
+    (eval/eval/*/…_eval.py, e.g. gqa_eval.py:108-117: do_sample / temperature / top_p / num_beams / max_new_tokens /
+    use_cache).  Prefill = the eval branch of prepare_inputs_labels_for_multimodal + the decoder with the per-sample in-LLM
+    SVA hook, K/V of every layer kept; decode steps = one token against the cache, no hook (cambrian_llama.py:174).
+    Greedy, or sampling with temperature -> top-k -> nucleus top-p as HF's logits warpers define them; returns the NEW
+    token ids [B, <= max_new_tokens] (like HF generate() called with inputs_embeds).  The reference inherits the loop from HF
+    GenerationMixin; what this loop does not implement RAISES instead of being dropped: beam search (``num_beams > 1``),
+    ``inputs_embeds`` (the reference raises too, cambrian_llama.py:447-448) and any keyword it does not know."""
+    if "inputs_embeds" in kwargs:
+        raise NotImplementedError("`inputs_embeds` is not supported")          # cambrian_llama.py:447-448
+    if num_beams is not None and int(num_beams) > 1:
+        raise NotImplementedError(f"generate(num_beams={num_beams}): beam search is not implemented in cambrian_amd "
+                                  "(greedy / temperature / top-k / top-p sampling only); pass num_beams=1")
+    if "max_length" in kwargs and kwargs["max_length"] is not None:
+        raise NotImplementedError("generate(max_length=...): use max_new_tokens")
+    kwargs.pop("max_length", None)
+    for k, v in kwargs.items():
+        ok = _GENERATE_ACCEPTED_NOOPS.get(k, ())
+        if k not in _GENERATE_ACCEPTED_NOOPS or (ok is not None and v not in ok):
+            raise ValueError(f"generate(): unsupported argument {k}={v!r} (cambrian_amd implements greedy / temperature / "
+                             "top_k / top_p decoding with a K/V cache)")
     with torch.no_grad():
         model = self.model
         if images is not None:
@@ -555,7 +600,8 @@ def _generate(self, inputs=None, images=None, image_sizes=None, max_new_tokens: 
         theta = float(getattr(self.config, "rope_theta", 10000.0))
         for step in range(max_new_tokens):
             if do_sample and temperature > 0:
-                nxt = torch.multinomial(torch.softmax(logits / temperature, -1), 1)[:, 0]
+                warped = filter_logits_top_k_top_p(logits / temperature, top_k, top_p)
+                nxt = torch.multinomial(torch.softmax(warped, -1), 1)[:, 0]
             else:
                 nxt = logits.argmax(-1)
             if eos_token_id is not None:

@@ -121,3 +121,21 @@ def test_generate_cached_decode_equals_full_reforward(dev, monkeypatch, lm, nkv)
         nxt = out.logits[0, -1].argmax().item()
         assert nxt == toks[0, t].item(), f"token {t}: cached decode {toks[0, t].item()} vs full re-forward {nxt}"
         cur = torch.cat([cur, torch.tensor([[nxt]], device=dev)], 1)
+
+
+def test_generate_with_the_eval_scripts_arguments(dev, monkeypatch):
+    """The argument set of eval/eval/gqa/gqa_eval.py:108-117.  A vanishing nucleus (top_p -> 0) keeps only the most probable
+    token, so sampling then reproduces the greedy tokens; beam search raises instead of being ignored."""
+    model, cfg, towers = _build(dev, torch.float32, monkeypatch, lm="llama", nkv=2)
+    model.eval()
+    ids, att, sizes, images = _eval_batch(dev, torch.float32, towers)
+    ids, sizes, images = ids[:1], sizes[1:2], [i[1:2] for i in images]
+    kw = dict(images=[i.to(dev) for i in images], image_sizes=sizes, max_new_tokens=3, use_cache=True)
+    greedy = model.generate(ids.to(dev), do_sample=False, temperature=0, top_p=None, num_beams=1, **kw)
+    nucleus = model.generate(ids.to(dev), do_sample=True, temperature=0.7, top_p=1e-6, num_beams=1, **kw)
+    assert torch.equal(greedy, nucleus)
+    torch.manual_seed(0)
+    sampled = model.generate(ids.to(dev), do_sample=True, temperature=0.7, top_p=0.9, num_beams=1, **kw)
+    assert sampled.shape == (1, 3)
+    with pytest.raises(NotImplementedError):
+        model.generate(ids.to(dev), num_beams=4, **kw)
