@@ -714,7 +714,7 @@ def main():
         m = model.model
         mods = list(m.layers)
         in_units = {id(p) for mod in mods for p in mod.parameters()}
-        z3_units = zero3_wrap(mods)
+        z3_units = zero3_wrap(mods, gradient_checkpointing=bool(cfg.gradient_checkpointing))
         rest = [p for p in params if id(p) not in in_units]
         opt = torch.optim.AdamW(zero3_parameters(z3_units) + rest, lr=1e-4, weight_decay=0.0, fused=True)
         sync = GradSync(rest, bucket_mb=args.bucket_mb) if rest else None

@@ -558,6 +558,18 @@ extern "C" int cmb_abi_version(void) { return CMB_ABI_VERSION; }
 int g_cmb_knobs[CMB_KNOB_COUNT] = {CMB_KNOB_DEFAULTS};
 extern "C" int cmb_knob_set(int32_t knob, int32_t value) {
   if (knob < 0 || knob >= CMB_KNOB_COUNT) return CMB_ERR_BAD_ARG;
+  // every knob has a closed value set: a typo in an A/B run must fail here, not launch a bogus grid or silently select
+  // another variant
+  bool ok = false;
+  switch (knob) {
+    case CMB_KNOB_LN_FWD: ok = value >= 0 && value <= 65536; break;           // 0 / 1 / workgroup cap
+    case CMB_KNOB_DWCONV: ok = value >= 0 && value <= 4096; break;            // 0 / 1 / rows per chunk
+    case CMB_KNOB_VIT_ATTN: ok = value == 0 || value == 1; break;
+    case CMB_KNOB_SVA_ABS: ok = value == 0 || value == 1; break;
+    case CMB_KNOB_LN_MULTI_CHUNK: ok = value == 4 || value == 7; break;
+    default: ok = value >= 0; break;
+  }
+  if (!ok) return CMB_ERR_BAD_ARG;
   g_cmb_knobs[knob] = value;
   return CMB_OK;
 }

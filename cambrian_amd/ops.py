@@ -708,6 +708,8 @@ def layernorm(x, gamma, beta, eps: float = 1e-5):
 
 
 DEFER_LN_BWD = os.environ.get("CAMBRIAN_AMD_DEFER_LN_BWD", "1") != "0"   # (A/B runs: 0 = one LayerNorm backward per SVA layer)
+# parked layers per flush (= the 4-layer launches of cmb_layernorm_bwd_multi; 0 = only when the shared-gradient node runs)
+DEFER_LN_FLUSH = int(os.environ.get("CAMBRIAN_AMD_DEFER_LN_FLUSH", "4"))
 
 
 class GradAccumulator:
@@ -725,13 +727,36 @@ class GradAccumulator:
         self.buf: Optional[torch.Tensor] = None
         self.shape = None
         self.defer = False
-        self.pos_index = {}     # data_ptr of an announced position table -> its slot in SharedGradFn's inputs
+        self.pos_index = {}     # id() of an announced position table (the Parameter object) -> its slot in SharedGradFn's inputs
         self.deferred = []      # (dn, x, mean, rstd, add fp32 | None, side, grid_r, slot | -1)
+        self.pos_meta = []      # (shape, dtype, needs grad) per announced table
+        self.dpos = []          # fp32 table gradients filled by flush()
 
     def get(self, rows: int, D: int, device) -> torch.Tensor:
         if self.buf is None:
             self.buf = torch.zeros((rows, D), dtype=torch.float32, device=device)
         return self.buf
+
+    def flush(self) -> None:
+        """Run the parked LayerNorm backwards (one cmb_layernorm_bwd_multi call per window geometry) into the shared fp32
+        buffer and release their gradient tensors.  Called by SvaNormFn.backward whenever DEFER_LN_FLUSH layers are parked
+        (= the kernel's 4-layer launches: same launches as one call at the end, but at most 4 layers' d(x-hat) — 1.8 GB at
+        24 images instead of 5.9 GB — are alive at a time) and by SharedGradFn.backward for the rest."""
+        items, self.deferred = self.deferred, []
+        if not items:
+            return
+        x = items[0][1]
+        groups = {}
+        for dn, _x, mean, rstd, add, side, grid_r, slot in items:
+            if slot >= 0 and self.dpos[slot] is None and self.pos_meta[slot][2]:
+                self.dpos[slot] = torch.zeros(self.pos_meta[slot][0], dtype=torch.float32, device=x.device)
+            groups.setdefault((side, grid_r) if add is not None else (1, 1), []).append((dn, mean, rstd, add, slot))
+        have = self.buf is not None
+        if self.buf is None:
+            self.buf = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        for (side, grid_r), its in groups.items():
+            k_layernorm_bwd_multi(x, its, side, grid_r, self.buf, have, self.dpos)
+            have = True
 
 
 def k_layernorm_bwd_multi(x: torch.Tensor, items, side: int, grid_r: int, dx: torch.Tensor, accumulate: bool, dadd_out):
@@ -765,34 +790,22 @@ class SharedGradFn(torch.autograd.Function):
         ctx.holder = holder
         holder.shape = x.shape
         holder.defer = DEFER_LN_BWD
-        holder.pos_index = {p.data_ptr(): i for i, p in enumerate(pos_params)}
         holder.deferred = []
+        holder.pos_meta = [(tuple(p.shape), p.dtype, bool(ctx.needs_input_grad[2 + i])) for i, p in enumerate(pos_params)]
+        holder.dpos = [None] * len(pos_params)
         ctx.x_dtype = x.dtype
-        ctx.pos_meta = [(tuple(p.shape), p.dtype) for p in pos_params]
+        ctx.n_pos = len(pos_params)
         ctx.set_materialize_grads(False)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
         h = ctx.holder
-        buf, items = h.buf, h.deferred
-        h.buf, h.deferred = None, []
-        dpos = [None] * len(ctx.pos_meta)
-        if items:
-            x = items[0][1]
-            groups = {}
-            for dn, _x, mean, rstd, add, side, grid_r, slot in items:
-                if slot >= 0 and dpos[slot] is None and ctx.needs_input_grad[2 + slot]:
-                    dpos[slot] = torch.zeros(ctx.pos_meta[slot][0], dtype=torch.float32, device=x.device)
-                groups.setdefault((side, grid_r) if add is not None else (1, 1), []).append((dn, mean, rstd, add, slot))
-            have = buf is not None
-            if buf is None:
-                buf = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-            for (side, grid_r), its in groups.items():
-                k_layernorm_bwd_multi(x, its, side, grid_r, buf, have, dpos)
-                have = True
-            dpos = [None if t is None else (t if ctx.pos_meta[i][1] == torch.float32 else t.to(ctx.pos_meta[i][1]))
-                    for i, t in enumerate(dpos)]
+        h.flush()
+        buf, h.buf = h.buf, None
+        dpos = [None if t is None else (t if h.pos_meta[i][1] == torch.float32 else t.to(h.pos_meta[i][1]))
+                for i, t in enumerate(h.dpos)] + [None] * (ctx.n_pos - len(h.dpos))
+        h.dpos = [None] * ctx.n_pos
         if buf is None:
             return (g, None, *dpos)
         if g is not None:
@@ -801,6 +814,14 @@ class SharedGradFn(torch.autograd.Function):
 
 
 def shared_grad(x: torch.Tensor, holder: GradAccumulator, pos_params=()) -> torch.Tensor:
+    # tables are recognised by the IDENTITY of the tensor object handed to sva_norm(), not by their storage address: a
+    # sharded / re-materialised parameter (ZeRO-3: storage.resize_(0), every released table at data_ptr 0) keeps its id but
+    # not its address, and two tables must never alias
+    pos_params = tuple(pos_params)
+    index = {id(p): i for i, p in enumerate(pos_params)}
+    if len(index) != len(pos_params):
+        raise L.CambrianAmdError("shared_grad: the same position table was announced twice")
+    holder.pos_index = index
     return SharedGradFn.apply(x, holder, *pos_params)
 
 
@@ -810,11 +831,11 @@ class SvaNormFn(torch.autograd.Function):
     the shared fp32 accumulator instead of being returned."""
 
     @staticmethod
-    def forward(ctx, x, pos, holder: GradAccumulator, side: int, grid_r: int, eps: float):
+    def forward(ctx, x, pos, holder: GradAccumulator, side: int, grid_r: int, eps: float, pos_key=None):
         add = None if pos is None else k_cast(pos, torch.float32)
         n, mean, rstd = k_layernorm_fwd(x, None, None, eps, add=add, side=side, grid_r=grid_r)
         ctx.holder, ctx.side, ctx.grid_r = holder, side, grid_r
-        ctx.pos_key = None if pos is None else pos.data_ptr()
+        ctx.pos_key = pos_key          # id() of the table object the caller passed (sva_norm)
         ctx.pos_dtype = None if pos is None else pos.dtype
         ctx.has_pos = pos is not None
         if pos is None:
@@ -837,7 +858,9 @@ class SvaNormFn(torch.autograd.Function):
             if slot != -2 and not (h.deferred and h.deferred[0][1].data_ptr() != x.data_ptr()):
                 # parked: SharedGradFn.backward runs every layer's LayerNorm backward in one pass and returns d(pos)
                 h.deferred.append((dn, x, mean, rstd, add, ctx.side, ctx.grid_r, slot))
-                return None, None, None, None, None, None
+                if DEFER_LN_FLUSH > 0 and len(h.deferred) >= DEFER_LN_FLUSH:
+                    h.flush()
+                return None, None, None, None, None, None, None
         dpos = None
         if need_x:
             acc = h.get(x.shape[0], x.shape[1], x.device)
@@ -847,11 +870,11 @@ class SvaNormFn(torch.autograd.Function):
             _, _, _, dpos = k_layernorm_bwd(dn, x, mean, rstd, add=add, side=ctx.side, grid_r=ctx.grid_r)
         if dpos is not None and ctx.pos_dtype != torch.float32:
             dpos = dpos.to(ctx.pos_dtype)
-        return None, dpos, None, None, None, None
+        return None, dpos, None, None, None, None, None
 
 
 def sva_norm(x, pos, holder, side, grid_r, eps=1e-5):
-    return SvaNormFn.apply(x, pos, holder, side, grid_r, eps)
+    return SvaNormFn.apply(x, pos, holder, side, grid_r, eps, None if pos is None else id(pos))
 
 
 # ================================================================================================
@@ -1210,7 +1233,9 @@ class EmbedSpliceFn(torch.autograd.Function):
             t = torch.arange(S, device=dout.device)[None]
             p_b = pos.to(torch.int64)[:, None]
             text = (p_b < 0) | (t < p_b) | (t >= p_b + side * (side + 1))
-            idx = torch.where(ids == image_token, torch.zeros_like(ids), ids)[text]
+            # the same id map as embed_splice_fwd_kernel: the image token -> row 0, everything else clamped into the table
+            # (a pad / ignore id such as -100 reads row 0 in the forward; it must add to row 0 here, not assert)
+            idx = torch.where(ids == image_token, torch.zeros_like(ids), ids).clamp_(0, V - 1)[text]
             dtable = torch.zeros((V, H), dtype=torch.float32, device=dout.device)
             dtable.index_add_(0, idx, dout[text].float())
             dtable = dtable.to(tab_dtype)

@@ -89,11 +89,18 @@ class Zero3Unit:
 
     # ---- forward -------------------------------------------------------------------------------------------------
     @staticmethod
+    def recompute_probe_available() -> bool:
+        return getattr(torch._C, "_current_graph_task_id", None) is not None
+
+    @staticmethod
     def _recomputing() -> bool:
         """True while autograd is executing a backward pass: a forward of the module seen then is the activation
         recompute of a non-reentrant ``torch.utils.checkpoint`` region around it (cambrian_llama.py wraps every decoder
-        layer in one when ``gradient_checkpointing`` is set; the reference: train_fsdp.py:1299-1304 under FSDP)."""
-        probe = getattr(torch._C, "_current_graph_task_id", None)   # private; absent -> the recompute case is not recognised
+        layer in one when ``gradient_checkpointing`` is set; the reference: train_fsdp.py:1299-1304 under FSDP).  The probe
+        is a private torch API: ``zero3_wrap(..., gradient_checkpointing=True)`` REFUSES to build units when it is missing
+        (a recompute forward taken for a new forward would release the unit's storage under its own backward: wrong
+        results, not an error — ADVICE r4)."""
+        probe = getattr(torch._C, "_current_graph_task_id", None)
         return probe is not None and probe() != -1
 
     def _pre_forward(self, module, args) -> None:
@@ -255,9 +262,14 @@ class Zero3Unit:
 
 
 def zero3_wrap(modules: Iterable[nn.Module], process_group: Optional[dist.ProcessGroup] = None,
-               prefetch: bool = True) -> List[Zero3Unit]:
+               prefetch: bool = True, gradient_checkpointing: bool = False) -> List[Zero3Unit]:
     """One unit per module, chained in the given (= call) order; ``prefetch`` starts each unit's all-gather while its
-    predecessor (forward) / successor (backward) computes."""
+    predecessor (forward) / successor (backward) computes.  ``gradient_checkpointing``: the wrapped modules will be
+    re-computed inside their backward (non-reentrant checkpoint) — needs Zero3Unit's recompute probe, raises without it."""
+    if gradient_checkpointing and not Zero3Unit.recompute_probe_available():
+        raise RuntimeError("zero3_wrap: this torch build has no torch._C._current_graph_task_id, so a ZeRO-3 unit cannot tell "
+                           "an activation re-computation from a new forward; run ZeRO-3 without gradient checkpointing, or "
+                           "use ZeRO-2 (cambrian_amd.train.zero)")
     units = [Zero3Unit(m, process_group) for m in modules]
     for i, u in enumerate(units):
         u.chain, u.index, u.prefetch = units, i, bool(prefetch)

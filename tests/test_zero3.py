@@ -245,3 +245,14 @@ def test_zero3_under_activation_recompute():
     for u, w in zip(units, want):
         for a, b in zip(u.full_state(), w):
             assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+
+
+def test_zero3_refuses_recompute_without_the_probe(monkeypatch):
+    """ZeRO-3 under activation re-computation needs torch's graph-task probe to tell a recompute forward from a new one; a
+    torch build without it must be refused at wrap time, not run into released storage."""
+    import torch
+    from cambrian_amd.train.zero3 import Zero3Unit, zero3_wrap
+    m = torch.nn.Linear(4, 4)
+    monkeypatch.setattr(Zero3Unit, "recompute_probe_available", staticmethod(lambda: False))
+    with pytest.raises(RuntimeError, match="re-computation"):
+        zero3_wrap([m], gradient_checkpointing=True)
