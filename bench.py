@@ -721,6 +721,12 @@ def main():
     elif args.zero2:
         from cambrian_amd.train.zero import Zero2AdamW
         opt, sync = Zero2AdamW(params, lr=1e-4, weight_decay=0.0, bucket_mb=args.bucket_mb), None
+    elif args.stage == "finetune":
+        # fp32 masters + fp32 moments for the bf16 decoder (the reference: fp32 FSDP parameters, bf16 compute —
+        # train_fsdp.py:1324-1326, fsdp_config.json:6): 16 B per parameter; ZeRO-2 / ZeRO-3 above shard the same state
+        from cambrian_amd.train.master import MasterAdamW
+        opt = MasterAdamW(params, lr=4e-5, weight_decay=0.0)
+        sync = GradSync(params, bucket_mb=args.bucket_mb)
     else:
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
         sync = GradSync(params, bucket_mb=args.bucket_mb)
@@ -929,6 +935,8 @@ def main():
             line["config"]["workload"] = line["config"]["workload"].replace(
                 "pre-training stage (SVA+projectors train, LLM+towers frozen)", "FINETUNE stage (LLM + SVA + projectors train, towers frozen)")
             line["config"]["trainable_parameters"] = int(sum(p.numel() for p in params))
+            line["config"]["optimizer_state"] = ("fp32 master weights + fp32 AdamW moments for the bf16 decoder (16 B / parameter"
+                                                 + (", sharded 1 / world" if (args.zero2 or args.zero3) else "") + "), lr 4e-5")
             line["config"]["gradient_buckets"] = (len(sync.buckets) if sync is not None else len(getattr(opt, "buckets", [])))
         if cfg.gradient_checkpointing:
             line["config"]["activation_recomputation"] = "decoder layers + in-LLM SVA layers (non-reentrant checkpoint)"

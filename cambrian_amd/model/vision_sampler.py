@@ -149,10 +149,12 @@ class VisionCrossAttentionLayer(nn.Module):
     def _absorbed_tower(self, qh: torch.Tensor, feats) -> int:
         """Index of the tower whose K / V projections are absorbed into the query side, or -1: bf16 (MFMA kernels) or fp32
         (the exact instantiation of the same algorithm: the fp32 parity path runs what the bench line runs), 16 heads x 64 over
-        1024-wide features, exactly one windowed tower (2 x 2 ... 4 x 4 keys) beside at most four one-key towers, fp8
-        projections off (that mode quantises the per-token K|V GEMM this path removes).  CAMBRIAN_AMD_ABSORB_KV=0 keeps
-        the per-token projection (A/B runs)."""
-        if not ABSORB_KV or qh.dtype not in (torch.bfloat16, torch.float32) or self.hidden_dim != 1024 or ops._FP8_LINEAR:
+        1024-wide features, exactly one windowed tower (2 x 2 ... 4 x 4 keys) beside at most four one-key towers.
+        ``config.fp8_projections`` COMPOSES with it (round 5): the windowed tower's K / V projections do not exist on this
+        path, so the fp8 forward GEMMs are the ones that remain per token — the one-key towers' K|V projections and the aux
+        projectors — and switching the mode on no longer selects the slower per-token algorithm.
+        CAMBRIAN_AMD_ABSORB_KV=0 keeps the per-token projection (A/B runs)."""
+        if not ABSORB_KV or qh.dtype not in (torch.bfloat16, torch.float32) or self.hidden_dim != 1024:
             return -1
         big = [i for i, s in enumerate(self.kv_size_list) if s > 1]
         if len(big) != 1 or self.kv_size_list[big[0]] > 4 or len(self.kv_size_list) - 1 > 4:

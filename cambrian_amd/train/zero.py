@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 
 class _ZBucket:
-    def __init__(self, params: List[torch.nn.Parameter], world: int, rank: int):
+    def __init__(self, params: List[torch.nn.Parameter], world: int, rank: int, master_dtype: Optional[torch.dtype] = None):
         self.params = params
         dev, dt = params[0].device, params[0].dtype
         n = sum(p.numel() for p in params)
@@ -42,6 +42,12 @@ class _ZBucket:
         lo = rank * self.shard_len
         self.param_shard = self.flat_param[lo:lo + self.shard_len]
         self.grad_shard = torch.zeros(self.shard_len, device=dev, dtype=dt)
+        # fp32 master of the OWNED shard when the bucket computes in a narrower type (the reference up-casts every FSDP
+        # parameter to fp32 before sharding and computes in bf16: train_fsdp.py:1324-1326, fsdp_config.json:6): AdamW steps on
+        # the master, the compute-dtype shard is its cast, refreshed after every step and all-gathered from there
+        self.master_shard = None
+        if master_dtype is not None and dt != master_dtype and dt.is_floating_point:
+            self.master_shard = self.param_shard.detach().to(master_dtype).clone()
         self.pending = len(params)
         self.work = None
         self.dirty = False  # flat_grad holds something since it was last zeroed (set by every accumulation)
@@ -51,7 +57,12 @@ class Zero2AdamW:
     """Sharded-gradient, sharded-state AdamW (decoupled weight decay, same update rule as torch.optim.AdamW)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, bucket_mb: float = 64.0, process_group: Optional[dist.ProcessGroup] = None):
+                 weight_decay: float = 0.0, bucket_mb: float = 64.0, process_group: Optional[dist.ProcessGroup] = None,
+                 master_dtype: Optional[torch.dtype] = torch.float32):
+        """``master_dtype``: parameters of a narrower floating type (a bf16 decoder in the finetune stage) get an fp32 master
+        copy of the owned shard, fp32 AdamW moments and a cast back per step — 16 B per parameter / world, the accounting of
+        BASELINE configs[3] / [4]; ``None`` steps in the parameter's own dtype (the round-4 behaviour: at lr 4e-5 most
+        updates of a bf16 parameter vanish below its ulp, tests/test_master_weights.py)."""
         self.group = process_group
         on = dist.is_initialized()
         self.world = dist.get_world_size(process_group) if on else 1
@@ -63,14 +74,15 @@ class Zero2AdamW:
         for p in plist:
             nbytes = p.numel() * p.element_size()
             if cur and (cur_bytes + nbytes > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
-                self.buckets.append(_ZBucket(cur, self.world, self.rank))
+                self.buckets.append(_ZBucket(cur, self.world, self.rank, master_dtype))
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self.buckets.append(_ZBucket(cur, self.world, self.rank))
+            self.buckets.append(_ZBucket(cur, self.world, self.rank, master_dtype))
         # optimizer state exists for the owned shards only
-        self._shards = [torch.nn.Parameter(b.param_shard, requires_grad=True) for b in self.buckets]
+        self._shards = [torch.nn.Parameter(b.param_shard if b.master_shard is None else b.master_shard, requires_grad=True)
+                        for b in self.buckets]
         fused = self._shards[0].is_cuda if self._shards else False
         self.inner = torch.optim.AdamW(self._shards, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                        **({"fused": True} if fused else {}))
@@ -134,9 +146,13 @@ class Zero2AdamW:
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-            s.grad = b.grad_shard if self.world == 1 else b.grad_shard.div_(self.world)
+            g = b.grad_shard if self.world == 1 else b.grad_shard.div_(self.world)
+            s.grad = g if b.master_shard is None else g.to(b.master_shard.dtype)
         self.inner.step()
-        for b in self.buckets:
+        for b, s in zip(self.buckets, self._shards):
+            if b.master_shard is not None:
+                b.param_shard.copy_(b.master_shard)   # the compute-dtype shard = the master's cast
+                s.grad = None                           # (the up-cast gradient copy is per step)
             if self.world > 1:
                 gathers.append(dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=self.group, async_op=True))
             b.flat_grad.zero_()
@@ -163,8 +179,12 @@ class Zero2AdamW:
             s_.grad = None
 
     def state_bytes(self) -> int:
-        """optimizer-state bytes held by THIS rank (2 fp32 moments per owned element)."""
-        return sum(2 * b.shard_len * b.param_shard.element_size() for b in self.buckets)
+        """optimizer-state bytes held by THIS rank: two moments per owned element in the stepping dtype (+ the master copy)."""
+        tot = 0
+        for b in self.buckets:
+            step_t = b.param_shard if b.master_shard is None else b.master_shard
+            tot += 2 * b.shard_len * step_t.element_size() + (0 if b.master_shard is None else b.shard_len * b.master_shard.element_size())
+        return tot
 
     def remove(self) -> None:
         for h in self._handles:

@@ -33,7 +33,13 @@ import torch.nn as nn
 
 
 class Zero3Unit:
-    def __init__(self, module: nn.Module, process_group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, module: nn.Module, process_group: Optional[dist.ProcessGroup] = None,
+                 master_dtype: Optional[torch.dtype] = torch.float32):
+        """``master_dtype``: a TRAINABLE unit whose parameters compute in a narrower floating type keeps its owned shard as an
+        fp32 master (``unit.shard``, what the optimizer steps on — fp32 moments follow); the all-gather sends the master's
+        cast straight into the compute-dtype flat buffer and the reduce-scattered gradient is accumulated in fp32: the
+        reference's XLA-FSDP run (fp32 parameters sharded, bf16 compute: train_fsdp.py:1324-1326, fsdp_config.json:6).
+        ``None``: the shard stays in the compute dtype (round-4 behaviour).  Frozen units never carry a master."""
         self.module = module
         self.group = process_group
         on = dist.is_initialized()
@@ -64,7 +70,9 @@ class Zero3Unit:
         lo = self.rank * self.shard_len
         self.trainable = any(p.requires_grad for p in self.params)
         self.n_trainable = sum(1 for p in self.params if p.requires_grad)
-        self.shard = nn.Parameter(self.full[lo:lo + self.shard_len].clone(), requires_grad=self.trainable)
+        own = self.full[lo:lo + self.shard_len].clone()
+        self.master = bool(self.trainable and master_dtype is not None and dt != master_dtype and dt.is_floating_point)
+        self.shard = nn.Parameter(own.to(master_dtype) if self.master else own, requires_grad=self.trainable)
         self._nbytes = self.full.untyped_storage().nbytes()
         self._resident = True
         self._work = None          # in-flight asynchronous all-gather into self.full (prefetch)
@@ -158,7 +166,8 @@ class Zero3Unit:
     def _issue(self, async_op: bool) -> None:
         self.full.untyped_storage().resize_(self._nbytes)
         if self.world > 1:
-            w = dist.all_gather_into_tensor(self.full, self.shard.data, group=self.group, async_op=async_op)
+            src = self.shard.data.to(self.full.dtype) if self.master else self.shard.data   # the master's cast is what travels
+            w = dist.all_gather_into_tensor(self.full, src, group=self.group, async_op=async_op)
             self._work = w if async_op else None
         else:
             self.full[: self.shard_len].copy_(self.shard.data)
@@ -233,6 +242,8 @@ class Zero3Unit:
             g.div_(self.world)
         else:
             g = flat[: self.shard_len].clone()
+        if self.master:
+            g = g.to(self.shard.dtype)
         self.shard.grad = g if self.shard.grad is None else self.shard.grad + g
         self.release()
         self._pending = 0
@@ -262,7 +273,8 @@ class Zero3Unit:
 
 
 def zero3_wrap(modules: Iterable[nn.Module], process_group: Optional[dist.ProcessGroup] = None,
-               prefetch: bool = True, gradient_checkpointing: bool = False) -> List[Zero3Unit]:
+               prefetch: bool = True, gradient_checkpointing: bool = False,
+               master_dtype: Optional[torch.dtype] = torch.float32) -> List[Zero3Unit]:
     """One unit per module, chained in the given (= call) order; ``prefetch`` starts each unit's all-gather while its
     predecessor (forward) / successor (backward) computes.  ``gradient_checkpointing``: the wrapped modules will be
     re-computed inside their backward (non-reentrant checkpoint) — needs Zero3Unit's recompute probe, raises without it."""
@@ -270,7 +282,7 @@ def zero3_wrap(modules: Iterable[nn.Module], process_group: Optional[dist.Proces
         raise RuntimeError("zero3_wrap: this torch build has no torch._C._current_graph_task_id, so a ZeRO-3 unit cannot tell "
                            "an activation re-computation from a new forward; run ZeRO-3 without gradient checkpointing, or "
                            "use ZeRO-2 (cambrian_amd.train.zero)")
-    units = [Zero3Unit(m, process_group) for m in modules]
+    units = [Zero3Unit(m, process_group, master_dtype) for m in modules]
     for i, u in enumerate(units):
         u.chain, u.index, u.prefetch = units, i, bool(prefetch)
     return units

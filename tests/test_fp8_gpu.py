@@ -112,3 +112,42 @@ def test_linear_fp8_forward_bf16_backward(dev):
         y4 = ops.linear(x, w.detach()[:, :], b, heavy=True)     # a view: quantised per call, never cached
         assert len(ops._FP8_WEIGHT_CACHE) == n0 and torch.equal(y4, y3)
     assert rel_err(y3, 2 * (exact - b.detach()) + b.detach()) < 6e-2
+
+
+def test_fp8_projections_compose_with_the_absorbed_path(dev):
+    """``fp8_projections`` must not select the slower per-token K|V algorithm.  A 1024-wide SVA layer with one
+    one-key tower and one 4 x 4-window tower: under the fp8 context the windowed tower still takes the absorbed path (no K|V
+    projection exists for it to quantise), the one-key tower's K|V GEMM runs in fp8; forward and feature gradients stay
+    within fp8 tolerance of the bf16 run."""
+    from cambrian_amd import ops
+    from cambrian_amd.model.vision_sampler import VisionTokenSampler
+    from oracle import sva as O
+    gen = torch.Generator().manual_seed(0)
+    kv_sizes, B, qside, hidden = [1, 4], 1, 4, 1024
+    p = O.init_sampler_params(hidden, hidden, [hidden] * 2, kv_sizes, hidden, 1, gen)
+    m = VisionTokenSampler(hidden, hidden, [hidden] * 2, kv_sizes, hidden, 1)
+    m.load_state_dict(p, strict=True)
+    m = m.to(dev)
+    Bq = B * qside * qside
+    q = torch.randn(Bq, hidden, generator=gen).to(dev, torch.bfloat16)
+    ctx = torch.randn(B, hidden, generator=gen).to(dev, torch.bfloat16)
+    feats = [torch.randn(B * (qside * s) ** 2, hidden, generator=gen) for s in kv_sizes]
+    masks = [torch.ones(Bq, s * s, dtype=torch.uint8, device=dev) for s in kv_sizes]
+    taken = []
+    layer = m.layers[0]
+    orig = layer._absorbed_tower
+    layer._absorbed_tower = lambda qh, fs: taken.append(orig(qh, fs)) or taken[-1]
+    res = {}
+    for mode in (False, True):
+        holders = [ops.GradAccumulator() for _ in kv_sizes]
+        fd = [f.to(dev, torch.bfloat16).requires_grad_() for f in feats]
+        shared = [ops.shared_grad(f, h, m.pos_tables(i)) for i, (f, h) in enumerate(zip(fd, holders))]
+        with ops.fp8_projections(mode):
+            out = m.forward_fused(q, ctx, shared, masks, holders, B, qside)
+        out.float().sum().backward()
+        res[mode] = (out.detach().float(), [f.grad.float() for f in fd])
+    assert taken == [1, 1], taken                      # the windowed tower is absorbed in BOTH modes
+    assert rel_err(res[True][0], res[False][0]) < 6e-2
+    assert not torch.equal(res[True][0], res[False][0])    # the fp8 GEMM really ran
+    for g8, g16 in zip(res[True][1], res[False][1]):
+        assert rel_err(g8, g16) < 1e-1
