@@ -262,15 +262,16 @@ def cpu_baseline():
 
 
 def reference_cpu_run():
-    """profiles/r02_cpu_reference_baseline.json as the bench line's cpu_baseline object (kind "reference")."""
-    path = os.path.join(ROOT, "profiles", "r02_cpu_reference_baseline.json")
+    """The newest profiles/rNN_cpu_reference_baseline.json as the bench line's cpu_baseline object (kind "reference")."""
+    import glob
     try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_cpu_reference_baseline.json")))[-1]
         with open(path) as f:
             d = json.load(f)
         return {"value": d["images_per_s"], "unit": "images/s (tower+SVA part of the step, B = 1, fp32)", "cores": d["cores"],
                 "kind": "reference", "host": d.get("host"), "sample": d["what"], "parts_s": d["parts"],
-                "measured_where": "build container (same image as the GPU box; /root/reference is not shipped to the GPU box), "
-                                  "read from profiles/r02_cpu_reference_baseline.json — not timed in this run",
+                "measured_where": f"build container (same image as the GPU box; /root/reference is not shipped to the GPU box), "
+                                  f"read from profiles/{os.path.basename(path)} (timed {d.get('timed_on', 'in round 2')}) — not timed in this run",
                 "source": "tools/cpu_reference_baseline.py"}
     except Exception:
         return None

@@ -260,6 +260,214 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Forward, software-pipelined inside the wave (round 5; knob CMB_KNOB_FLASH = 1, the default).  flash_fwd_kernel above runs
+// a tile as S = K Q^T (MFMA) -> softmax (VALU) -> O += V P (MFMA), each phase waiting for the one before: the SQ counters
+// showed the matrix pipe 32 % busy and a wave waiting 29-44 % of its cycles (profiles/r04_pmc_flash.jsonl).  Here the S
+// product of tile t + 1 is issued in the same basic block as the exponentials of tile t, and the row maximum of tile t + 1 in
+// the same block as the P V product of tile t, so the scheduler (and the hardware: MFMA and VALU issue independently) overlaps
+// them: K lives in two LDS buffers (tile t + 1 is staged while tile t is still being read), S in two register sets.
+// Same arithmetic in the same order per element as flash_fwd_kernel (bit-identical output; tests/test_flash_bwd_gpu.py).
+// Tiles that need a mask (the wave's diagonal tiles, padded keys) take their max after the block, un-overlapped.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL, bool MASKED>
+__global__ void __launch_bounds__(256, 2) flash_fwd_pipe_kernel(const FlashParams p, bf16_t* __restrict__ out,
+                                                                float* __restrict__ lse_out) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[2][64 * LDR];
+  __shared__ __attribute__((aligned(16))) bf16_t sVT[HD * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 5, j = lane & 31;
+  const int nqb = p.S / 128;
+  const FlashBlock fb = flash_block_qh((int)blockIdx.x, (int)gridDim.x, flash_items(nqb, CAUSAL), p.H, p.HKV);
+  const int b = fb.b, h = fb.h, hk = fb.hk;
+  const int nrep = flash_pair_count(nqb, fb.blk, CAUSAL);
+  for (int rep = 0; rep < nrep; ++rep) {
+  const int qb = flash_pair_q(nqb, fb.blk, rep, CAUSAL);
+  const int q0 = qb * 128 + wave * 32;
+  const int qi = q0 + j;
+  const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + g * 8);
+  const float c2 = p.scale * LOG2E;
+  const bf16_t* kbase = p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
+  const bf16_t* vbase = p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
+  f32x16_t acc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int nt = CAUSAL ? (qb * 128 + 128) / 64 : (p.kv_len + 63) / 64;
+  const int t_last = CAUSAL ? (q0 + 31) / 64 : nt - 1;   // the last tile that holds an open key for some query of this wave
+
+  // S^T of one 64-key tile from the K image at kbuf (two 32-key halves, 8 k-steps each)
+  auto s_product = [&](const bf16_t* kbuf, f32x16_t (&s)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kbuf + (kt * 32 + j) * LDR + ks * 16 + g * 8);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      }
+    }
+  };
+  // does tile t need a mask for some query of this wave (diagonal / ragged end / padded keys)?
+  auto edge_tile = [&](int t, uint64_t vw) -> bool {
+    return (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) || (MASKED && vw != ~0ull);
+  };
+  auto apply_mask = [&](int t, uint64_t vw, f32x16_t (&s)[2]) __attribute__((always_inline)) {
+    if (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[kt][r] = -INFINITY;
+        }
+    }
+    if (MASKED && vw != ~0ull) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const uint32_t w = flash_open_bits(vw, kt, g, qi - (t * 64 + kt * 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (!(w & (1u << ((r & 3) + 8 * (r >> 2))))) s[kt][r] = -INFINITY;
+      }
+    }
+  };
+  auto row_max = [&](const f32x16_t (&s)[2]) __attribute__((always_inline)) -> float {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    return fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;   // c2 > 0: max of the scaled scores
+  };
+  // P = exp2(S c2 - m_new) in place, row sum into l, converted to the four B operands of the P V product
+  auto exp_block = [&](f32x16_t (&s)[2], float m_new, bf16x8_t (&pf)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, -m_new));
+        l += pv;
+        s[kt][r] = pv;
+      }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int kt = kb >> 1, hh = kb & 1;
+      pf[kb] = cvt8(s[kt][8 * hh + 0], s[kt][8 * hh + 1], s[kt][8 * hh + 2], s[kt][8 * hh + 3], s[kt][8 * hh + 4],
+                    s[kt][8 * hh + 5], s[kt][8 * hh + 6], s[kt][8 * hh + 7]);
+    }
+  };
+  auto pv_product = [&](const bf16x8_t (&pf)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int kt = kb >> 1, hh = kb & 1;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const bf16_t* vrow = sVT + (d * 32 + j) * LDT + kt * 32 + 16 * hh + 4 * g;
+        const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(vrow);
+        const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(vrow + 8);
+        bf16x8_t vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb], acc[d], 0, 0, 0);  // O^T[d][query]
+      }
+    }
+  };
+
+  TileRegs rk, rv;
+  tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
+  tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
+  uint8_t vb = MASKED ? kv_byte(p, b, 0, lane) : (uint8_t)1;  // key-padding byte of this lane's key of the NEXT tile
+  __syncthreads();                               // the previous rep's reads of both K buffers are done
+  tile_put<true, false>(rk, sK[0], nullptr, tid);
+  __syncthreads();
+  if (nt > 1) tile_load(rk, kbase, p.kv_ss, 64, p.S, tid);
+  f32x16_t s[2];          // S^T of the current tile (raw scores), then its probabilities
+  float m_new = -INFINITY;  // running maximum INCLUDING the current tile (valid when the current tile is live)
+  uint64_t vw_cur = MASKED ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
+  s_product(sK[0], s);
+  {   // tile 0's maximum (tile 0 is live for every wave; it is an edge tile only for the first query block)
+    if (edge_tile(0, vw_cur)) apply_mask(0, vw_cur, s);
+    m_new = fmaxf(m, row_max(s));
+  }
+  bool cur_live = !(MASKED && vw_cur == 0 && 63 < q0);   // (a tile of padding below the diagonal adds nothing)
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();  // (A) tile t - 1's V^T reads are done; K buffer (t + 1) & 1 was last read two iterations ago
+    tile_put<false, true>(rv, nullptr, sVT, tid);
+    if (t + 1 < nt) tile_put<true, false>(rk, sK[(t + 1) & 1], nullptr, tid);
+    __syncthreads();  // (B)
+    if (t + 2 < nt) tile_load(rk, kbase, p.kv_ss, (t + 2) * 64, p.S, tid);
+    uint64_t vw_next = ~0ull;
+    if (t + 1 < nt) {
+      tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
+      if (MASKED) {
+        vb = kv_byte(p, b, t + 1, lane);
+        vw_next = __builtin_amdgcn_ballot_w64(vb != 0);
+      }
+    }
+    const bool have_next = t + 1 <= t_last && t + 1 < nt;
+    const bool next_live = have_next && !(MASKED && vw_next == 0 && (t + 1) * 64 + 63 < q0);
+    const bool next_edge = next_live && edge_tile(t + 1, vw_next);
+    const bf16_t* kn = sK[(t + 1) & 1];
+    if (cur_live && t <= t_last) {
+      if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+      }
+      m = m_new;
+      bf16x8_t pf[4];
+      if (next_live && !next_edge) {        // the common case: one block, everything of both tiles in it
+        f32x16_t sn[2];
+        s_product(kn, sn);                  //   MFMA: S of tile t + 1
+        exp_block(s, m_new, pf);            //   VALU: P of tile t
+        pv_product(pf);                     //   MFMA: O += V P of tile t
+        m_new = fmaxf(m, row_max(sn));      //   VALU: row maximum of tile t + 1
+        s[0] = sn[0]; s[1] = sn[1];
+      } else if (next_live) {               // tile t + 1 needs a mask before its maximum
+        f32x16_t sn[2];
+        s_product(kn, sn);
+        exp_block(s, m_new, pf);
+        pv_product(pf);
+        apply_mask(t + 1, vw_next, sn);
+        m_new = fmaxf(m, row_max(sn));
+        s[0] = sn[0]; s[1] = sn[1];
+      } else {                              // the wave's last live tile (or tile t + 1 is all padding)
+        exp_block(s, m_new, pf);
+        pv_product(pf);
+      }
+    } else if (next_live) {                 // tile t was skipped (padding) but tile t + 1 is live
+      s_product(kn, s);
+      if (next_edge) apply_mask(t + 1, vw_next, s);
+      m_new = fmaxf(m, row_max(s));
+    }
+    cur_live = next_live;
+  }
+  const float l_tot = l + __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l_tot;
+  bf16_t* orow = out + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      bf16x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[d][4 * qd + e] * inv);
+      *reinterpret_cast<bf16x4_t*>(orow + d * 32 + 8 * qd + 4 * g) = o;
+    }
+  if (g == 0) lse_out[((int64_t)b * p.H + h) * p.S + qi] = (m + __builtin_amdgcn_logf(l_tot)) * (1.0f / LOG2E);
+  }  // rep
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // dQ: grid S/128 * H * B (1-D, flash_block_qh), 256 threads.  lane = (query j = lane & 31 of the wave's 32, half g = lane >> 5).
 // ------------------------------------------------------------------------------------------------------------------
 // MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
@@ -649,12 +857,16 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.key_valid = causal ? key_valid : nullptr;
   const int64_t nqb = S / 128;
   const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal != 0) * H * B));   // 1-D: flash_map.h
-  if (causal && p.key_valid)
-    hipLaunchKernelGGL((flash_fwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
-  else if (causal)
-    hipLaunchKernelGGL((flash_fwd_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
-  else
-    hipLaunchKernelGGL((flash_fwd_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
+  const bool pipe = cmb_knob(CMB_KNOB_FLASH) != 0;   // 1 (default): the in-wave pipelined kernels; 0: the round-4 kernels
+#define FLASH_FWD_LAUNCH(C_, M_)                                                                                          \
+  do {                                                                                                                    \
+    if (pipe) hipLaunchKernelGGL((flash_fwd_pipe_kernel<C_, M_>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse); \
+    else hipLaunchKernelGGL((flash_fwd_kernel<C_, M_>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);    \
+  } while (0)
+  if (causal && p.key_valid) FLASH_FWD_LAUNCH(true, true);
+  else if (causal) FLASH_FWD_LAUNCH(true, false);
+  else FLASH_FWD_LAUNCH(false, false);
+#undef FLASH_FWD_LAUNCH
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

@@ -13,7 +13,7 @@ cores, fp32, B = 1, at the release-8B dimensions:
     the release dimensions (CLIPVisionModel L/14@336, SiglipVisionModel SO400M/14@384, Dinov2Model giant@378,
     ConvNextModel XXL widths @1024), forward only (frozen, no_grad — as in the reference run).
 
-Writes profiles/r02_cpu_reference_baseline.json; bench.py reports it as cpu_baseline.reference_run.
+Writes profiles/<round>_cpu_reference_baseline.json (dated; round 5 re-timed it: r05_cpu_reference_baseline.json); bench.py reports it as cpu_baseline.reference_run.
 """
 from __future__ import annotations
 
@@ -173,7 +173,9 @@ def main():
     out["what"] = ("towers forward (HF stand-ins) + real prepare_inputs_labels_for_multimodal fwd+bwd (aux projectors, "
                    "3-layer connector, mm_projector, splice) + 10 x real in-LLM VisionTokenSampler layer fwd+bwd; the LLM "
                    "decoder itself is not part of the tower+SVA path")
-    path = os.path.join(ROOT, "profiles", "r02_cpu_reference_baseline.json")
+    out["timed_on"] = time.strftime("%Y-%m-%d %H:%M:%S %Z")
+    out["round"] = os.environ.get("CAMBRIAN_ROUND", "r05")
+    path = os.path.join(ROOT, "profiles", f"{out['round']}_cpu_reference_baseline.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
