@@ -121,7 +121,17 @@ __device__ __forceinline__ void tile_put(const TileRegs& r, bf16_t* sR, bf16_t* 
 // ------------------------------------------------------------------------------------------------------------------
 // MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
 // registers or code (with a run-time pointer test instead they ran 3-8 % slower although every tile took the all-valid path).
-template <bool CAUSAL, bool MASKED>
+// PIPE (round 5, knob CMB_KNOB_FLASH = 1): the LDS fragment reads of the two products run a ring of four fragments AHEAD of
+// the MFMAs that consume them, in a fixed order (FLASH_FENCE = scheduling barrier).  Left to itself hipcc reuses eight fragment
+// registers: ds_read x 2, s_waitcnt, MFMA, s_waitcnt, MFMA, then the next two reads — every pair of MFMAs waits out a full
+// LDS round trip, and all eight products of a 32-key half chain on one accumulator (the assembly of the round-4 kernel,
+// profiles/r05_lab.md).  Here read i + 4 is issued right behind MFMA i and consecutive MFMAs alternate between the two
+// halves' accumulators.  Same products, same accumulation order per accumulator: bit-identical results.
+// (A cross-tile variant — S of tile t + 1 in the same basic block as the exponentials of tile t, two K buffers — was built
+// first and measured SLOWER, 460 vs 397 us at 8 x 2048 tokens: 256 registers with spills, and the compiler's interleave still
+// waited for every read.)
+#define FLASH_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <bool CAUSAL, bool MASKED, bool PIPE>
 __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, bf16_t* __restrict__ out,
                                                            float* __restrict__ lse_out) {
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
@@ -170,6 +180,25 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
     if (CAUSAL && t * 64 > q0 + 31) continue;
     if (MASKED && vw == 0 && t * 64 + 63 < q0) continue;  // a tile of padding below the wave's diagonal: nothing to add
     f32x16_t s[2];
+    if (PIPE) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      // product i = 2 ks + kt: K rows of half kt, k-step ks
+      const bf16_t* kb0 = sK + j * LDR + g * 8;
+      bf16x8_t kr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kr[i] = *reinterpret_cast<const bf16x8_t*>(kb0 + (i & 1) * 32 * LDR + (i >> 1) * 16);
+      FLASH_FENCE();
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[i >> 1], s[i & 1], 0, 0, 0);
+        if (i + 4 < 2 * KS)
+          kr[i & 3] = *reinterpret_cast<const bf16x8_t*>(kb0 + ((i + 4) & 1) * 32 * LDR + ((i + 4) >> 1) * 16);
+        FLASH_FENCE();
+      }
+    } else {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -179,6 +208,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
         const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + (kt * 32 + j) * LDR + ks * 16 + g * 8);
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
       }
+    }
     }
     // VALU budget: this block runs once per 32 MFMAs of the wave, so every instruction per score element counts.
     // The mask is applied only on tiles that can hold a masked key for some query of the wave (the diagonal tiles /
@@ -226,6 +256,36 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
         l += pv;
         s[kt][r] = pv;
       }
+    if (PIPE) {
+      bf16x8_t pf[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int kt = kb >> 1, hh = kb & 1;
+        pf[kb] = cvt8(s[kt][8 * hh + 0], s[kt][8 * hh + 1], s[kt][8 * hh + 2], s[kt][8 * hh + 3], s[kt][8 * hh + 4],
+                      s[kt][8 * hh + 5], s[kt][8 * hh + 6], s[kt][8 * hh + 7]);
+      }
+      // product i = 4 kb + d: V^T rows of d tile d, keys 16 kb .. 16 kb + 15 of the tile (two 8-byte reads per fragment)
+      const bf16_t* vb0 = sVT + j * LDT + 4 * g;
+      bf16x4_t vlo[4], vhi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vlo[i] = *reinterpret_cast<const bf16x4_t*>(vb0 + (i & 3) * 32 * LDT + (i >> 2) * 16);
+        vhi[i] = *reinterpret_cast<const bf16x4_t*>(vb0 + (i & 3) * 32 * LDT + (i >> 2) * 16 + 8);
+      }
+      FLASH_FENCE();
+#pragma unroll
+      for (int i = 0; i < 4 * DT; ++i) {
+        bf16x8_t vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = vlo[i & 3][e]; vf[4 + e] = vhi[i & 3][e]; }
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[i >> 2], acc[i & 3], 0, 0, 0);  // O^T[d][query]
+        if (i + 4 < 4 * DT) {
+          vlo[i & 3] = *reinterpret_cast<const bf16x4_t*>(vb0 + ((i + 4) & 3) * 32 * LDT + ((i + 4) >> 2) * 16);
+          vhi[i & 3] = *reinterpret_cast<const bf16x4_t*>(vb0 + ((i + 4) & 3) * 32 * LDT + ((i + 4) >> 2) * 16 + 8);
+        }
+        FLASH_FENCE();
+      }
+    } else {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int kt = kb >> 1, hh = kb & 1;
@@ -242,214 +302,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_kernel(const FlashParams p, 
         acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, acc[d], 0, 0, 0);  // O^T[d][query]
       }
     }
-  }
-  const float l_tot = l + __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l_tot;
-  bf16_t* orow = out + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
-#pragma unroll
-  for (int d = 0; d < DT; ++d)
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      bf16x4_t o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[d][4 * qd + e] * inv);
-      *reinterpret_cast<bf16x4_t*>(orow + d * 32 + 8 * qd + 4 * g) = o;
     }
-  if (g == 0) lse_out[((int64_t)b * p.H + h) * p.S + qi] = (m + __builtin_amdgcn_logf(l_tot)) * (1.0f / LOG2E);
-  }  // rep
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Forward, software-pipelined inside the wave (round 5; knob CMB_KNOB_FLASH = 1, the default).  flash_fwd_kernel above runs
-// a tile as S = K Q^T (MFMA) -> softmax (VALU) -> O += V P (MFMA), each phase waiting for the one before: the SQ counters
-// showed the matrix pipe 32 % busy and a wave waiting 29-44 % of its cycles (profiles/r04_pmc_flash.jsonl).  Here the S
-// product of tile t + 1 is issued in the same basic block as the exponentials of tile t, and the row maximum of tile t + 1 in
-// the same block as the P V product of tile t, so the scheduler (and the hardware: MFMA and VALU issue independently) overlaps
-// them: K lives in two LDS buffers (tile t + 1 is staged while tile t is still being read), S in two register sets.
-// Same arithmetic in the same order per element as flash_fwd_kernel (bit-identical output; tests/test_flash_bwd_gpu.py).
-// Tiles that need a mask (the wave's diagonal tiles, padded keys) take their max after the block, un-overlapped.
-// ------------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL, bool MASKED>
-__global__ void __launch_bounds__(256, 2) flash_fwd_pipe_kernel(const FlashParams p, bf16_t* __restrict__ out,
-                                                                float* __restrict__ lse_out) {
-  __shared__ __attribute__((aligned(16))) bf16_t sK[2][64 * LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t sVT[HD * LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 5, j = lane & 31;
-  const int nqb = p.S / 128;
-  const FlashBlock fb = flash_block_qh((int)blockIdx.x, (int)gridDim.x, flash_items(nqb, CAUSAL), p.H, p.HKV);
-  const int b = fb.b, h = fb.h, hk = fb.hk;
-  const int nrep = flash_pair_count(nqb, fb.blk, CAUSAL);
-  for (int rep = 0; rep < nrep; ++rep) {
-  const int qb = flash_pair_q(nqb, fb.blk, rep, CAUSAL);
-  const int q0 = qb * 128 + wave * 32;
-  const int qi = q0 + j;
-  const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
-  bf16x8_t qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + g * 8);
-  const float c2 = p.scale * LOG2E;
-  const bf16_t* kbase = p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
-  const bf16_t* vbase = p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh;
-  f32x16_t acc[DT];
-#pragma unroll
-  for (int d = 0; d < DT; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
-  float m = -INFINITY, l = 0.f;
-  const int nt = CAUSAL ? (qb * 128 + 128) / 64 : (p.kv_len + 63) / 64;
-  const int t_last = CAUSAL ? (q0 + 31) / 64 : nt - 1;   // the last tile that holds an open key for some query of this wave
-
-  // S^T of one 64-key tile from the K image at kbuf (two 32-key halves, 8 k-steps each)
-  auto s_product = [&](const bf16_t* kbuf, f32x16_t (&s)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kbuf + (kt * 32 + j) * LDR + ks * 16 + g * 8);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kt], 0, 0, 0);
-      }
-    }
-  };
-  // does tile t need a mask for some query of this wave (diagonal / ragged end / padded keys)?
-  auto edge_tile = [&](int t, uint64_t vw) -> bool {
-    return (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) || (MASKED && vw != ~0ull);
-  };
-  auto apply_mask = [&](int t, uint64_t vw, f32x16_t (&s)[2]) __attribute__((always_inline)) {
-    if (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-          if (!(CAUSAL ? key <= qi : key < p.kv_len)) s[kt][r] = -INFINITY;
-        }
-    }
-    if (MASKED && vw != ~0ull) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const uint32_t w = flash_open_bits(vw, kt, g, qi - (t * 64 + kt * 32));
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (!(w & (1u << ((r & 3) + 8 * (r >> 2))))) s[kt][r] = -INFINITY;
-      }
-    }
-  };
-  auto row_max = [&](const f32x16_t (&s)[2]) __attribute__((always_inline)) -> float {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-    return fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;   // c2 > 0: max of the scaled scores
-  };
-  // P = exp2(S c2 - m_new) in place, row sum into l, converted to the four B operands of the P V product
-  auto exp_block = [&](f32x16_t (&s)[2], float m_new, bf16x8_t (&pf)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, -m_new));
-        l += pv;
-        s[kt][r] = pv;
-      }
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int kt = kb >> 1, hh = kb & 1;
-      pf[kb] = cvt8(s[kt][8 * hh + 0], s[kt][8 * hh + 1], s[kt][8 * hh + 2], s[kt][8 * hh + 3], s[kt][8 * hh + 4],
-                    s[kt][8 * hh + 5], s[kt][8 * hh + 6], s[kt][8 * hh + 7]);
-    }
-  };
-  auto pv_product = [&](const bf16x8_t (&pf)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int kt = kb >> 1, hh = kb & 1;
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const bf16_t* vrow = sVT + (d * 32 + j) * LDT + kt * 32 + 16 * hh + 4 * g;
-        const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(vrow);
-        const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(vrow + 8);
-        bf16x8_t vf;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb], acc[d], 0, 0, 0);  // O^T[d][query]
-      }
-    }
-  };
-
-  TileRegs rk, rv;
-  tile_load(rk, kbase, p.kv_ss, 0, p.S, tid);
-  tile_load(rv, vbase, p.kv_ss, 0, p.S, tid);
-  uint8_t vb = MASKED ? kv_byte(p, b, 0, lane) : (uint8_t)1;  // key-padding byte of this lane's key of the NEXT tile
-  __syncthreads();                               // the previous rep's reads of both K buffers are done
-  tile_put<true, false>(rk, sK[0], nullptr, tid);
-  __syncthreads();
-  if (nt > 1) tile_load(rk, kbase, p.kv_ss, 64, p.S, tid);
-  f32x16_t s[2];          // S^T of the current tile (raw scores), then its probabilities
-  float m_new = -INFINITY;  // running maximum INCLUDING the current tile (valid when the current tile is live)
-  uint64_t vw_cur = MASKED ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
-  s_product(sK[0], s);
-  {   // tile 0's maximum (tile 0 is live for every wave; it is an edge tile only for the first query block)
-    if (edge_tile(0, vw_cur)) apply_mask(0, vw_cur, s);
-    m_new = fmaxf(m, row_max(s));
-  }
-  bool cur_live = !(MASKED && vw_cur == 0 && 63 < q0);   // (a tile of padding below the diagonal adds nothing)
-  for (int t = 0; t < nt; ++t) {
-    __syncthreads();  // (A) tile t - 1's V^T reads are done; K buffer (t + 1) & 1 was last read two iterations ago
-    tile_put<false, true>(rv, nullptr, sVT, tid);
-    if (t + 1 < nt) tile_put<true, false>(rk, sK[(t + 1) & 1], nullptr, tid);
-    __syncthreads();  // (B)
-    if (t + 2 < nt) tile_load(rk, kbase, p.kv_ss, (t + 2) * 64, p.S, tid);
-    uint64_t vw_next = ~0ull;
-    if (t + 1 < nt) {
-      tile_load(rv, vbase, p.kv_ss, (t + 1) * 64, p.S, tid);
-      if (MASKED) {
-        vb = kv_byte(p, b, t + 1, lane);
-        vw_next = __builtin_amdgcn_ballot_w64(vb != 0);
-      }
-    }
-    const bool have_next = t + 1 <= t_last && t + 1 < nt;
-    const bool next_live = have_next && !(MASKED && vw_next == 0 && (t + 1) * 64 + 63 < q0);
-    const bool next_edge = next_live && edge_tile(t + 1, vw_next);
-    const bf16_t* kn = sK[(t + 1) & 1];
-    if (cur_live && t <= t_last) {
-      if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        l *= alpha;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
-      }
-      m = m_new;
-      bf16x8_t pf[4];
-      if (next_live && !next_edge) {        // the common case: one block, everything of both tiles in it
-        f32x16_t sn[2];
-        s_product(kn, sn);                  //   MFMA: S of tile t + 1
-        exp_block(s, m_new, pf);            //   VALU: P of tile t
-        pv_product(pf);                     //   MFMA: O += V P of tile t
-        m_new = fmaxf(m, row_max(sn));      //   VALU: row maximum of tile t + 1
-        s[0] = sn[0]; s[1] = sn[1];
-      } else if (next_live) {               // tile t + 1 needs a mask before its maximum
-        f32x16_t sn[2];
-        s_product(kn, sn);
-        exp_block(s, m_new, pf);
-        pv_product(pf);
-        apply_mask(t + 1, vw_next, sn);
-        m_new = fmaxf(m, row_max(sn));
-        s[0] = sn[0]; s[1] = sn[1];
-      } else {                              // the wave's last live tile (or tile t + 1 is all padding)
-        exp_block(s, m_new, pf);
-        pv_product(pf);
-      }
-    } else if (next_live) {                 // tile t was skipped (padding) but tile t + 1 is live
-      s_product(kn, s);
-      if (next_edge) apply_mask(t + 1, vw_next, s);
-      m_new = fmaxf(m, row_max(s));
-    }
-    cur_live = next_live;
   }
   const float l_tot = l + __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -472,8 +325,8 @@ __global__ void __launch_bounds__(256, 2) flash_fwd_pipe_kernel(const FlashParam
 // ------------------------------------------------------------------------------------------------------------------
 // MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
 // registers or code (with a run-time pointer test instead they ran 3-8 % slower although every tile took the all-valid path).
-template <bool CAUSAL, bool MASKED>
-__global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const FlashParams p) {
+template <bool CAUSAL, bool MASKED, bool PIPE>
+__global__ void __launch_bounds__(256, (CAUSAL && !PIPE) ? 2 : 1) flash_dq_kernel(const FlashParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * LDR];
   __shared__ __attribute__((aligned(16))) bf16_t sV[64 * LDR];
   __shared__ __attribute__((aligned(16))) bf16_t sKT[HD * LDT];
@@ -541,9 +394,7 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
     }
     if (CAUSAL && t * 64 > q0 + 31) continue;  // whole tile above this wave's diagonal (block-uniform barriers stay matched)
     if (MASKED && vw == 0 && t * 64 + 63 < q0) continue;  // padding only, below the diagonal
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      f32x16_t s, dp;
+    auto sdp = [&](int kt, f32x16_t& s, f32x16_t& dp) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
@@ -553,6 +404,8 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);      // S^T[key][query]
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);   // dP^T[key][query]
       }
+    };
+    auto mask_s = [&](int kt, f32x16_t& s) __attribute__((always_inline)) {
       // mask only where the tile can hold a masked key for some query of the wave; one fma feeds exp2
       if (CAUSAL ? (t * 64 + kt * 32 + 31 > q0) : (t * 64 + kt * 32 + 32 > p.kv_len)) {
 #pragma unroll
@@ -567,6 +420,8 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
         for (int r = 0; r < 16; ++r)
           if (!(w & (1u << ((r & 3) + 8 * (r >> 2))))) s[r] = -INFINITY;
       }
+    };
+    auto ds_dq = [&](int kt, f32x16_t& s, const f32x16_t& dp) __attribute__((always_inline)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lse2));
@@ -586,6 +441,101 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
           for (int e = 0; e < 4; ++e) { tf[e] = lo[e]; tf[4 + e] = hi[e]; }
           acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf, acc[d], 0, 0, 0);  // dQ^T[d][query]
         }
+      }
+    };
+    const bool edge = (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) || (MASKED && vw != ~0ull);
+    if (PIPE && !edge) {
+      // Round 5 (knob CMB_KNOB_FLASH = 1), interior tiles: the dK/dV kernel's arrangement (see there) — four phases in a fixed
+      // order, every MFMA followed by the LDS read of the fragment four products ahead and by a slice of the other half's
+      // exponentials:  A  S0, dP0   B  S1, dP1 + dS0   C  dQ0 + dS1 (two elements per product)   D  dQ1.
+      // This variant is compiled for one workgroup per CU (the second set of score registers does not fit 256).
+      f32x16_t s0, dp0, s1, dp1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; dp0[r] = 0.f; s1[r] = 0.f; dp1[r] = 0.f; }
+      // product i = 2 ks + w of a score phase: w = 0 S^T (K rows x Q fragment), w = 1 dP^T (V rows x dO fragment)
+      auto row_frag = [&](int kt, int i) __attribute__((always_inline)) -> bf16x8_t {
+        return *reinterpret_cast<const bf16x8_t*>(((i & 1) ? sV : sK) + (kt * 32 + j) * LDR + (i >> 1) * 16 + g * 8);
+      };
+      // product i = 4 kb + d of a dQ phase: K^T rows of d tile d, keys 16 kb .. of the half
+      auto tr_ptr = [&](int kt, int i) __attribute__((always_inline)) -> const bf16_t* {
+        return sKT + ((i & 3) * 32 + j) * LDT + kt * 32 + 16 * (i >> 2) + 4 * g;
+      };
+      auto elem = [&](int r, f32x16_t& s_, const f32x16_t& dp_) __attribute__((always_inline)) {
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s_[r], c2, -lse2));
+        s_[r] = pr * (dp_[r] - dq_d);
+      };
+      bf16x8_t rf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rf[i] = row_frag(0, i);
+      FLASH_FENCE();
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {   // A
+        if (i & 1) dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], dof[i >> 1], dp0, 0, 0, 0);
+        else s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], qf[i >> 1], s0, 0, 0, 0);
+        rf[i & 3] = row_frag(i + 4 < 2 * KS ? 0 : 1, (i + 4) & (2 * KS - 1));
+        FLASH_FENCE();
+      }
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {   // B
+        if (i & 1) dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], dof[i >> 1], dp1, 0, 0, 0);
+        else s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], qf[i >> 1], s1, 0, 0, 0);
+        if (i + 4 < 2 * KS) rf[i & 3] = row_frag(1, i + 4);
+        elem(i, s0, dp0);
+        FLASH_FENCE();
+      }
+      bf16x8_t pf[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        pf[kb] = cvt8(s0[8 * kb + 0], s0[8 * kb + 1], s0[8 * kb + 2], s0[8 * kb + 3], s0[8 * kb + 4], s0[8 * kb + 5],
+                      s0[8 * kb + 6], s0[8 * kb + 7]);
+      bf16x4_t tlo[4], thi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16_t* q_ = tr_ptr(0, i);
+        tlo[i] = *reinterpret_cast<const bf16x4_t*>(q_);
+        thi[i] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+      }
+      FLASH_FENCE();
+#pragma unroll
+      for (int i = 0; i < 2 * DT; ++i) {   // C
+        bf16x8_t tf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { tf[e] = tlo[i & 3][e]; tf[4 + e] = thi[i & 3][e]; }
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[i >> 2], acc[i & 3], 0, 0, 0);
+        {
+          const bf16_t* q_ = tr_ptr(i + 4 < 2 * DT ? 0 : 1, (i + 4) & (2 * DT - 1));
+          tlo[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_);
+          thi[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+        }
+        elem(2 * i, s1, dp1);
+        elem(2 * i + 1, s1, dp1);
+        FLASH_FENCE();
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        pf[kb] = cvt8(s1[8 * kb + 0], s1[8 * kb + 1], s1[8 * kb + 2], s1[8 * kb + 3], s1[8 * kb + 4], s1[8 * kb + 5],
+                      s1[8 * kb + 6], s1[8 * kb + 7]);
+      FLASH_FENCE();
+#pragma unroll
+      for (int i = 0; i < 2 * DT; ++i) {   // D
+        bf16x8_t tf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { tf[e] = tlo[i & 3][e]; tf[4 + e] = thi[i & 3][e]; }
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[i >> 2], acc[i & 3], 0, 0, 0);
+        if (i + 4 < 2 * DT) {
+          const bf16_t* q_ = tr_ptr(1, i + 4);
+          tlo[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_);
+          thi[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+        }
+        FLASH_FENCE();
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x16_t s, dp;
+        sdp(kt, s, dp);
+        mask_s(kt, s);
+        ds_dq(kt, s, dp);
       }
     }
   }
@@ -610,7 +560,7 @@ __global__ void __launch_bounds__(256, CAUSAL ? 2 : 1) flash_dq_kernel(const Fla
 // ------------------------------------------------------------------------------------------------------------------
 // MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
 // registers or code (with a run-time pointer test instead they ran 3-8 % slower although every tile took the all-valid path).
-template <bool CAUSAL, bool MASKED>
+template <bool CAUSAL, bool MASKED, bool PIPE>
 __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);   // [64][LDR]
@@ -706,9 +656,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
         if (!(last_q && hq + 1 == group)) DKDV_LOAD(nh, nq);
       }
       if (CAUSAL && qt * 64 + 63 < k0) continue;  // every query of the tile precedes this wave's keys
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        f32x16_t s, dp;
+      // ---- one 64-query tile = two 32-query halves qs.  Pieces (all force-inlined; the same arithmetic in both orders):
+      auto sdp = [&](int qs, f32x16_t& s, f32x16_t& dp) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
@@ -718,9 +667,9 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);    // S[query][key]
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[ks], dp, 0, 0, 0);  // dP[query][key]
         }
-        f32x16_t pr;
-        // mask only where some key of the wave can be masked for some query of this 32-row half tile
-        const bool edge = (CAUSAL ? (k0 + 31 > qt * 64 + qs * 32) : (k0 + 32 > p.kv_len)) || wave_padded;
+      };
+      // pr = P, s = dP - D (in place of S)
+      auto probs = [&](int qs, f32x16_t& s, const f32x16_t& dp, f32x16_t& pr) __attribute__((always_inline)) {
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int qrow = qs * 32 + 8 * r4 + 4 * g;  // rows qrow .. qrow+3 <-> registers 4*r4 .. 4*r4+3
@@ -736,16 +685,18 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) s[4 * r4 + e] = dp[4 * r4 + e] - d4[e];
         }
-        // The mask as ONE wave-uniform block over the 16 probabilities: inside the element loop hipcc if-converted the
-        // test into a compare + select per element on EVERY tile (64 of the tile's ~680 vector / scalar instructions; one
-        // wave per SIMD pays each in full), while only the tiles on the diagonal (or holding padding) need it.
-        if (edge) {
+      };
+      // The mask as ONE wave-uniform block over the 16 probabilities: inside the element loop hipcc if-converted the
+      // test into a compare + select per element on EVERY tile (64 of the tile's ~680 vector / scalar instructions; one
+      // wave per SIMD pays each in full), while only the tiles on the diagonal (or holding padding) need it.
+      auto mask16 = [&](int qs, f32x16_t& pr) __attribute__((always_inline)) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int qidx = qt * 64 + qs * 32 + 8 * (r >> 2) + 4 * g + (r & 3);
-            if (!(CAUSAL ? (ki <= qidx && (kvalid || ki == qidx)) : ki < p.kv_len)) pr[r] = 0.f;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int qidx = qt * 64 + qs * 32 + 8 * (r >> 2) + 4 * g + (r & 3);
+          if (!(CAUSAL ? (ki <= qidx && (kvalid || ki == qidx)) : ki < p.kv_len)) pr[r] = 0.f;
         }
+      };
+      auto dvdk = [&](int qs, const f32x16_t& pr, f32x16_t& s) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = pr[r] * s[r];  // dS = P (dP - D)
 #pragma unroll
@@ -767,6 +718,133 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
             adv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, adv[d], 0, 0, 0);    // dV^T[d][key]
             adk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, adk[d], 0, 0, 0);  // dK^T[d][key]
           }
+        }
+      };
+      // mask only where some key of the wave can be masked for some query of a 32-row half tile
+      const bool edge0 = (CAUSAL ? (k0 + 31 > qt * 64) : (k0 + 32 > p.kv_len)) || wave_padded;
+      const bool edge1 = (CAUSAL ? (k0 + 31 > qt * 64 + 32) : (k0 + 32 > p.kv_len)) || wave_padded;
+      if (PIPE && !edge0 && !edge1) {
+        // Round 5 (knob CMB_KNOB_FLASH = 1), interior tiles.  One wave per SIMD has no other wave to fill its stalls, so the
+        // tile is issued as four phases of 16 MFMAs in a FIXED order (FLASH_FENCE): every MFMA is followed by the LDS read of
+        // the fragment four products ahead (ring of four) and by one element of the OTHER half's softmax arithmetic —
+        //   A  S0, dP0                        B  S1, dP1   + P0, dS0 (element i per product)
+        //   C  dV0, dK0  + P1, dS1            D  dV1, dK1
+        // — where hipcc's own order was read, read, wait, MFMA, wait, MFMA on eight fragment registers with the exponentials
+        // of a half strictly between its two groups of products (matrix pipe 30 % busy, the wave waiting 29-44 % of its
+        // cycles: profiles/r04_pmc_flash.jsonl).  Same operations on the same operands, same accumulation order: bit-identical.
+        f32x16_t s0, dp0, s1, dp1, pr0, pr1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; dp0[r] = 0.f; s1[r] = 0.f; dp1[r] = 0.f; }
+        f32x4_t lq[4], dq4[4];
+        // product i = 2 ks + w of a score phase: w = 0 S (Q rows x K fragment), w = 1 dP (dO rows x V fragment)
+        auto row_frag = [&](int qs, int i) __attribute__((always_inline)) -> bf16x8_t {
+          return *reinterpret_cast<const bf16x8_t*>(((i & 1) ? sDO : sQ) + (qs * 32 + j) * LDR + (i >> 1) * 16 + g * 8);
+        };
+        // product i = 8 qb16 + 2 d + w of a gradient phase: w = 0 dV (dO^T rows of d tile d), w = 1 dK (Q^T rows)
+        auto tr_ptr = [&](int qs, int i) __attribute__((always_inline)) -> const bf16_t* {
+          return ((i & 1) ? sQT : sDOT) + (((i >> 1) & 3) * 32 + j) * LDT + qs * 32 + 16 * (i >> 3) + 4 * g;
+        };
+        auto load_ld = [&](int qs) __attribute__((always_inline)) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            lq[r4] = *reinterpret_cast<const f32x4_t*>(sLse + qs * 32 + 8 * r4 + 4 * g);
+            dq4[r4] = *reinterpret_cast<const f32x4_t*>(sD + qs * 32 + 8 * r4 + 4 * g);
+          }
+        };
+        // element r of a half: pr = P, s = dS = P (dP - D)
+        auto elem = [&](int r, f32x16_t& s, const f32x16_t& dp, f32x16_t& pr) __attribute__((always_inline)) {
+          const float t = __builtin_fmaf(s[r], c2, -lq[r >> 2][r & 3]);
+          pr[r] = __builtin_amdgcn_exp2f(t);
+          const float u = dp[r] - dq4[r >> 2][r & 3];
+          s[r] = pr[r] * u;
+        };
+        bf16x8_t rf[4];
+        // ---- A: S0, dP0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rf[i] = row_frag(0, i);
+        FLASH_FENCE();
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) {
+          if (i & 1) dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], vf[i >> 1], dp0, 0, 0, 0);
+          else s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], kf[i >> 1], s0, 0, 0, 0);
+          rf[i & 3] = row_frag(i + 4 < 2 * KS ? 0 : 1, (i + 4) & (2 * KS - 1));   // runs on into phase B's first four
+          FLASH_FENCE();
+        }
+        load_ld(0);
+        FLASH_FENCE();
+        // ---- B: S1, dP1  +  the first half's probabilities
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) {
+          if (i & 1) dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], vf[i >> 1], dp1, 0, 0, 0);
+          else s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[i & 3], kf[i >> 1], s1, 0, 0, 0);
+          if (i + 4 < 2 * KS) rf[i & 3] = row_frag(1, i + 4);
+          elem(i, s0, dp0, pr0);
+          FLASH_FENCE();
+        }
+        bf16x8_t pf[2], dsf[2];
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          const int o8 = 8 * h8;
+          pf[h8] = cvt8(pr0[o8], pr0[o8 + 1], pr0[o8 + 2], pr0[o8 + 3], pr0[o8 + 4], pr0[o8 + 5], pr0[o8 + 6], pr0[o8 + 7]);
+          dsf[h8] = cvt8(s0[o8], s0[o8 + 1], s0[o8 + 2], s0[o8 + 3], s0[o8 + 4], s0[o8 + 5], s0[o8 + 6], s0[o8 + 7]);
+        }
+        load_ld(1);
+        bf16x4_t tlo[4], thi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16_t* q_ = tr_ptr(0, i);
+          tlo[i] = *reinterpret_cast<const bf16x4_t*>(q_);
+          thi[i] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+        }
+        FLASH_FENCE();
+        // ---- C: dV0, dK0  +  the second half's probabilities
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          bf16x8_t tf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { tf[e] = tlo[i & 3][e]; tf[4 + e] = thi[i & 3][e]; }
+          const int d = (i >> 1) & 3;
+          if (i & 1) adk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, dsf[i >> 3], adk[d], 0, 0, 0);
+          else adv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[i >> 3], adv[d], 0, 0, 0);
+          {
+            const bf16_t* q_ = tr_ptr(i + 4 < 16 ? 0 : 1, (i + 4) & 15);   // runs on into phase D's first four
+            tlo[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_);
+            thi[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+          }
+          elem(i, s1, dp1, pr1);
+          FLASH_FENCE();
+        }
+#pragma unroll
+        for (int h8 = 0; h8 < 2; ++h8) {
+          const int o8 = 8 * h8;
+          pf[h8] = cvt8(pr1[o8], pr1[o8 + 1], pr1[o8 + 2], pr1[o8 + 3], pr1[o8 + 4], pr1[o8 + 5], pr1[o8 + 6], pr1[o8 + 7]);
+          dsf[h8] = cvt8(s1[o8], s1[o8 + 1], s1[o8 + 2], s1[o8 + 3], s1[o8 + 4], s1[o8 + 5], s1[o8 + 6], s1[o8 + 7]);
+        }
+        FLASH_FENCE();
+        // ---- D: dV1, dK1
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          bf16x8_t tf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { tf[e] = tlo[i & 3][e]; tf[4 + e] = thi[i & 3][e]; }
+          const int d = (i >> 1) & 3;
+          if (i & 1) adk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, dsf[i >> 3], adk[d], 0, 0, 0);
+          else adv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[i >> 3], adv[d], 0, 0, 0);
+          if (i + 4 < 16) {
+            const bf16_t* q_ = tr_ptr(1, i + 4);
+            tlo[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_);
+            thi[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+          }
+          FLASH_FENCE();
+        }
+      } else {
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+          f32x16_t s, dp, pr;
+          sdp(qs, s, dp);
+          probs(qs, s, dp, pr);
+          if (qs == 0 ? edge0 : edge1) mask16(qs, pr);
+          dvdk(qs, pr, s);
         }
       }
     }
@@ -817,25 +895,29 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<true, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<false, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-      return CMB_ERR_LAUNCH;
+    bool ok = true;
+#define DKDV_ATTR(C_, M_, P_)                                                                                   \
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<C_, M_, P_>),                  \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess
+    DKDV_ATTR(true, true, false); DKDV_ATTR(true, false, false); DKDV_ATTR(false, false, false);
+    DKDV_ATTR(true, true, true); DKDV_ATTR(true, false, true); DKDV_ATTR(false, false, true);
+#undef DKDV_ATTR
+    if (!ok) return CMB_ERR_LAUNCH;
     attr_done = true;
   }
-  if (causal && p.key_valid) {
-    hipLaunchKernelGGL((flash_dq_kernel<true, true>), gq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((flash_dkdv_kernel<true, true>), gk, dim3(256), smem, s, p);
-  } else if (causal) {
-    hipLaunchKernelGGL((flash_dq_kernel<true, false>), gq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((flash_dkdv_kernel<true, false>), gk, dim3(256), smem, s, p);
-  } else {
-    hipLaunchKernelGGL((flash_dq_kernel<false, false>), gq, dim3(256), 0, s, p);
-    hipLaunchKernelGGL((flash_dkdv_kernel<false, false>), gk, dim3(256), smem, s, p);
-  }
+  // knob bits: 1 forward, 2 dQ, 4 dK/dV take the round-5 tile bodies (default 7); 0 = the round-4 kernels
+  const bool pipe_q = (cmb_knob(CMB_KNOB_FLASH) & 2) != 0, pipe_k = (cmb_knob(CMB_KNOB_FLASH) & 4) != 0;
+#define FLASH_BWD_LAUNCH(C_, M_)                                                                      \
+  do {                                                                                                \
+    if (pipe_q) hipLaunchKernelGGL((flash_dq_kernel<C_, M_, true>), gq, dim3(256), 0, s, p);          \
+    else hipLaunchKernelGGL((flash_dq_kernel<C_, M_, false>), gq, dim3(256), 0, s, p);                \
+    if (pipe_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, true>), gk, dim3(256), smem, s, p);     \
+    else hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, false>), gk, dim3(256), smem, s, p);           \
+  } while (0)
+  if (causal && p.key_valid) FLASH_BWD_LAUNCH(true, true);
+  else if (causal) FLASH_BWD_LAUNCH(true, false);
+  else FLASH_BWD_LAUNCH(false, false);
+#undef FLASH_BWD_LAUNCH
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }
@@ -857,11 +939,11 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.key_valid = causal ? key_valid : nullptr;
   const int64_t nqb = S / 128;
   const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal != 0) * H * B));   // 1-D: flash_map.h
-  const bool pipe = cmb_knob(CMB_KNOB_FLASH) != 0;   // 1 (default): the in-wave pipelined kernels; 0: the round-4 kernels
+  const bool pipe = (cmb_knob(CMB_KNOB_FLASH) & 1) != 0;   // bit 0 (default on): fragment reads run ahead of the MFMAs
 #define FLASH_FWD_LAUNCH(C_, M_)                                                                                          \
   do {                                                                                                                    \
-    if (pipe) hipLaunchKernelGGL((flash_fwd_pipe_kernel<C_, M_>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse); \
-    else hipLaunchKernelGGL((flash_fwd_kernel<C_, M_>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);    \
+    if (pipe) hipLaunchKernelGGL((flash_fwd_kernel<C_, M_, true>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse); \
+    else hipLaunchKernelGGL((flash_fwd_kernel<C_, M_, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);    \
   } while (0)
   if (causal && p.key_valid) FLASH_FWD_LAUNCH(true, true);
   else if (causal) FLASH_FWD_LAUNCH(true, false);
