@@ -1,0 +1,356 @@
+// flash2.hip — round-5 forward of the decoder's causal grouped-query attention (S = 2048, head_dim 128) for gfx950.
+// Same problem, same lane <-> element arrangement and the same products as flash_fwd_kernel (flash_bwd.hip: a LANE owns a
+// query, S^T = K Q^T, online softmax in base 2, O^T += V^T P^T, accumulator -> operand hand-off without shuffles); what
+// changed is how the operands reach the matrix pipe and in which order a wave issues its work:
+//   * K / V tiles (64 keys x 128) go global -> LDS by LDS-DMA (16 one-KiB pieces per tile, four per wave), un-padded and
+//     XOR-swizzled on the source side (flash_layout.h): no tile registers, no 16-bit shuffles, no ds_write — the round-4
+//     kernel spent ~80 of its ~230 vector instructions per tile and wave packing the transposed V image and 32 registers on
+//     the tile in flight.  V is consumed straight from the row-major image with transposing reads (ds_read_b64_tr_b16);
+//   * two K and two V buffers, ONE barrier per tile (the round-4 kernel: two): top of iteration t = "my pieces of K(t+1),
+//     V(t) have landed" (s_waitcnt vmcnt(0)) + barrier, then the DMA of K(t+2), V(t+1) goes out and flies for a whole tile;
+//   * the wave's two score sets: while the matrix pipe runs S(t+1) = K(t+1) Q^T the vector pipes exponentiate tile t, and
+//     while it runs O += V(t) P(t) they take the row maximum of tile t+1 — every MFMA is followed, in a FIXED order
+//     (FL_FENCE), by the LDS read of the fragment four products ahead and by its share of the other tile's softmax (<= 5
+//     instructions per MFMA, MI355X_MICROARCH.md: one wave hides about five single-issue instructions behind a 32 x 32 x 16
+//     MFMA).  The rescale decision of tile t+1 is taken after tile t's P V has completed and before tile t+1 is
+//     exponentiated (the safe order of cdna_hip_programming.md T13);
+//   * packed fp32 arithmetic for the exponent argument and the row sum (two partial sums per lane).
+// Tiles that need a mask (the wave's diagonal tiles, padded keys) take mask + maximum after the P V phase, un-overlapped.
+// Results agree with flash_fwd_kernel to fp32 rounding (the row sum is accumulated in two partial sums here), not bit for
+// bit; tests/test_flash_bwd_gpu.py holds both against fp32 autograd of the plain formula.
+#include <type_traits>
+#include "flash_common.h"
+#include "flash_layout.h"
+
+namespace cmb_flash {
+namespace {
+
+#define FL_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_v __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = FL_TILE_BYTES;            // 16 KiB
+constexpr int kSmemFwd = 4 * kTile;             // K ring (2) + V ring (2)
+
+__device__ __forceinline__ uint32_t cvt2(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, bf16x2_v));
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {
+  const uint64_t v = (uint64_t)q;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const char*)(((uint64_t)hi << 32) | lo);
+}
+// one LDS-DMA piece: 64 lanes x 16 bytes from base + voff (per lane) to LDS byte address lds (wave-uniform), lane-linear
+__device__ __forceinline__ void dma_piece(const char* base, uint32_t voff, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(base), "s"(lds)
+               : "memory", "m0");
+}
+
+template <bool CAUSAL, bool MASKED>
+__global__ void __launch_bounds__(256, 1) flash_fwd2_kernel(const FlashParams p, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse_out) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5, j = lane & 31;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem));
+  const int nqb = p.S / 128;
+  const FlashBlock fb = flash_block_qh((int)blockIdx.x, (int)gridDim.x, flash_items(nqb, CAUSAL), p.H, p.HKV);
+  const int b = fb.b, h = fb.h, hk = fb.hk;
+  const int nrep = flash_pair_count(nqb, fb.blk, CAUSAL);
+  const float c2 = p.scale * LOG2E;
+
+  // ---- per-lane constants of the operand tile (flash_layout.h)
+  // DMA: this wave's pieces 4 w .. 4 w + 3 of a tile (rows 16 w .. 16 w + 15)
+  uint32_t voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = 4 * wave + i;
+    voff[i] = (uint32_t)(fl_dma_row(piece, lane) * (int)(p.kv_ss * 2) + fl_dma_src_slot(piece, lane) * 16);
+  }
+  // row-major K fragments: product i = 2 ks + kt reads row 32 kt + j, logical slot 2 ks + g (rows 32 apart share the swizzle)
+  uint32_t kro[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kro[ks] = (uint32_t)fl_row_frag_off(0, ks, lane);
+  // transposed V fragments: product i = 4 kb + d reads rows 16 kb + ..., columns 32 d + j (16 rows further = + 4096 bytes)
+  uint32_t tro[DT][2];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) tro[d][r] = (uint32_t)fl_tr_frag_off(0, 32 * d, r, lane);
+
+  for (int rep = 0; rep < nrep; ++rep) {
+    const int qb = flash_pair_q(nqb, fb.blk, rep, CAUSAL);
+    const int q0 = qb * 128 + wave * 32;
+    const int qi = q0 + j;
+    const bf16_t* qrow = p.q + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + g * 8);
+    const char* kbase = uniform_ptr(reinterpret_cast<const char*>(p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh));
+    const char* vbase = uniform_ptr(reinterpret_cast<const char*>(p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh));
+    const int64_t tile_bytes = (int64_t)64 * p.kv_ss * 2;   // global bytes from one tile's first row to the next's
+    f32x16_t acc[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+    float m = -INFINITY;
+    f32x2_t l2 = {0.f, 0.f};
+    const int nt = CAUSAL ? (qb * 128 + 128) / 64 : (p.kv_len + 63) / 64;
+    const int t_last = CAUSAL ? (q0 + 31) / 64 : nt - 1;   // the last tile that holds an open key for some query of this wave
+
+    auto issue_k = [&](int t) {   // K tile t -> K buffer t & 1
+      const char* src = kbase + (int64_t)t * tile_bytes;
+      const uint32_t dst = lds0 + (uint32_t)((t & 1) * kTile) + (uint32_t)wave * 4096u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_piece(src, voff[i], dst + (uint32_t)i * 1024u);
+    };
+    auto issue_v = [&](int t) {   // V tile t -> V buffer t & 1
+      const char* src = vbase + (int64_t)t * tile_bytes;
+      const uint32_t dst = lds0 + (uint32_t)(2 * kTile + (t & 1) * kTile) + (uint32_t)wave * 4096u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma_piece(src, voff[i], dst + (uint32_t)i * 1024u);
+    };
+    auto kfrag = [&](const char* kbuf, int i) __attribute__((always_inline)) -> bf16x8_t {   // product i = 2 ks + kt
+      return *reinterpret_cast<const bf16x8_t*>(kbuf + kro[i >> 1] + (i & 1) * 32 * FL_ROW_BYTES);
+    };
+    auto vfrag_half = [&](const char* vbuf, int i, int r) __attribute__((always_inline)) -> s16x4_t {   // product i = 4 kb + d
+      return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vbuf + tro[i & 3][r] + (i >> 2) * 16 * FL_ROW_BYTES));
+    };
+    // does tile t need a mask for some query of this wave (diagonal / ragged end / padded keys)?
+    auto edge_tile = [&](int t, uint64_t vw) -> bool {
+      return (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) || (MASKED && vw != ~0ull);
+    };
+    auto apply_mask = [&](int t, uint64_t vw, f32x16_t& s0, f32x16_t& s1) __attribute__((always_inline)) {
+      if (CAUSAL ? (t * 64 + 63 > q0) : (t * 64 + 64 > p.kv_len)) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (!(CAUSAL ? key <= qi : key < p.kv_len)) (kt ? s1 : s0)[r] = -INFINITY;
+          }
+      }
+      if (MASKED && vw != ~0ull) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const uint32_t w = flash_open_bits(vw, kt, g, qi - (t * 64 + kt * 32));
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (!(w & (1u << ((r & 3) + 8 * (r >> 2))))) (kt ? s1 : s0)[r] = -INFINITY;
+        }
+      }
+    };
+    auto row_max = [&](const f32x16_t& s0, const f32x16_t& s1) __attribute__((always_inline)) -> float {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
+      return mx;
+    };
+    auto finish_max = [&](float mx) __attribute__((always_inline)) -> float {
+      return fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;   // c2 > 0: max of the scaled scores
+    };
+    // S^T of the tile at kbuf, nothing else (prologue / tile after a skipped one)
+    auto s_plain = [&](const char* kbuf, f32x16_t& s0, f32x16_t& s1) __attribute__((always_inline)) {
+      bf16x8_t kr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kr[i] = kfrag(kbuf, i);
+      FL_FENCE();
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        if (i < 2) (i ? s1 : s0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[0], (f32x16_t){0}, 0, 0, 0);
+        else (i & 1 ? s1 : s0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[i >> 1], (i & 1 ? s1 : s0), 0, 0, 0);
+        if (i + 4 < 2 * KS) kr[i & 3] = kfrag(kbuf, i + 4);
+        FL_FENCE();
+      }
+    };
+    // element pair (e, e + 1) of the current tile's scores -> probabilities (in place), row sum
+    auto exp_pair = [&](f32x16_t& s0, f32x16_t& s1, int e, f32x2_t nm2, f32x2_t c22) __attribute__((always_inline)) {
+      f32x16_t& s = (e < 16) ? s0 : s1;
+      const int r = e & 15;
+      const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s[r], s[r + 1]}, c22, nm2);
+      const f32x2_t pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      l2 += pv;
+      s[r] = pv[0];
+      s[r + 1] = pv[1];
+    };
+    // Phase 1: [S of the next tile] beside the exponentials of the current one
+    auto phase1 = [&](auto next_c, const char* kbuf, f32x16_t& c0, f32x16_t& c1, f32x16_t& n0, f32x16_t& n1, float m_new)
+        __attribute__((always_inline)) {
+      constexpr bool NEXT = decltype(next_c)::value;
+      const f32x2_t nm2 = {-m_new, -m_new}, c22 = {c2, c2};
+      bf16x8_t kr[4];
+      if (NEXT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kr[i] = kfrag(kbuf, i);
+      }
+      FL_FENCE();
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        if (NEXT) {
+          if (i < 2) (i ? n1 : n0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[0], (f32x16_t){0}, 0, 0, 0);
+          else (i & 1 ? n1 : n0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[i >> 1], (i & 1 ? n1 : n0), 0, 0, 0);
+          if (i + 4 < 2 * KS) kr[i & 3] = kfrag(kbuf, i + 4);
+        }
+        exp_pair(c0, c1, 2 * i, nm2, c22);
+        FL_FENCE();
+      }
+    };
+    // Phase 2: O += V P of the current tile beside [the row maximum of the next one]
+    auto phase2 = [&](auto max_c, const char* vbuf, const f32x16_t& c0, const f32x16_t& c1, const f32x16_t& n0,
+                      const f32x16_t& n1, float& mx) __attribute__((always_inline)) {
+      constexpr bool MAXN = decltype(max_c)::value;
+      auto pel = [&](int e) -> float { return e < 16 ? c0[e] : c1[e - 16]; };
+      auto nel = [&](int e) -> float { return e < 16 ? n0[e] : n1[e - 16]; };
+      u32x4_v pf[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pf[0][c] = cvt2(pel(2 * c), pel(2 * c + 1));
+      s16x4_t vlo[4], vhi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vlo[i] = vfrag_half(vbuf, i, 0);
+        vhi[i] = vfrag_half(vbuf, i, 1);
+      }
+      FL_FENCE();
+#pragma unroll
+      for (int i = 0; i < 4 * DT; ++i) {
+        const s16x8_t vv = {vlo[i & 3][0], vlo[i & 3][1], vlo[i & 3][2], vlo[i & 3][3],
+                            vhi[i & 3][0], vhi[i & 3][1], vhi[i & 3][2], vhi[i & 3][3]};
+        acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv),
+                                                              __builtin_bit_cast(bf16x8_t, pf[i >> 2]), acc[i & 3], 0, 0, 0);
+        if (i + 4 < 4 * DT) {
+          vlo[i & 3] = vfrag_half(vbuf, i + 4, 0);
+          vhi[i & 3] = vfrag_half(vbuf, i + 4, 1);
+        }
+        if (i < 12) {   // the operand of the NEXT key block: elements 8 (kb + 1) + 2 c, + 1 with c = i & 3
+          const int e = 8 * ((i >> 2) + 1) + 2 * (i & 3);
+          pf[(i >> 2) + 1][i & 3] = cvt2(pel(e), pel(e + 1));
+        }
+        if (MAXN) mx = fmaxf(fmaxf(mx, nel(2 * i)), nel(2 * i + 1));
+        FL_FENCE();
+      }
+    };
+
+    // ---- prologue: K(0), V(0), K(1) in flight; S(0) and its maximum
+    uint8_t vb = MASKED ? kv_byte(p, b, 0, lane) : (uint8_t)1;
+    __syncthreads();                    // the previous rep is done with every buffer
+    issue_k(0);
+    issue_v(0);
+    if (nt > 1) issue_k(1);
+    uint64_t vw_cur = MASKED ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
+    if (MASKED && nt > 1) vb = kv_byte(p, b, 1, lane);
+    if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K(0), V(0) landed (K(1)'s four pieces may fly on)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16_t sa0, sa1, sb0, sb1;   // two score sets (A = even tiles, B = odd tiles)
+    s_plain(smem, sa0, sa1);
+    if (edge_tile(0, vw_cur)) apply_mask(0, vw_cur, sa0, sa1);
+    float m_new = fmaxf(m, finish_max(row_max(sa0, sa1)));
+    bool cur_live = !(MASKED && vw_cur == 0 && 63 < q0);   // (a tile of padding below the diagonal adds nothing)
+
+    // one tile: (c0, c1) hold the scores of tile t, (n0, n1) receive those of tile t + 1
+    auto tile = [&](int t, f32x16_t& c0, f32x16_t& c1, f32x16_t& n0, f32x16_t& n1) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of K(t + 1), V(t) have landed
+      __syncthreads();                                   // everybody's have; everybody is done with K(t), V(t - 1)
+      if (t + 2 < nt) issue_k(t + 2);
+      uint64_t vw_next = ~0ull;
+      if (t + 1 < nt) {
+        issue_v(t + 1);
+        if (MASKED) {
+          vw_next = __builtin_amdgcn_ballot_w64(vb != 0);
+          if (t + 2 < nt) vb = kv_byte(p, b, t + 2, lane);
+        }
+      }
+      const bool next_live = (t + 1 <= t_last && t + 1 < nt) && !(MASKED && vw_next == 0 && (t + 1) * 64 + 63 < q0);
+      const bool next_edge = next_live && edge_tile(t + 1, vw_next);
+      const char* kn = smem + ((t + 1) & 1) * kTile;
+      const char* vc = smem + 2 * kTile + (t & 1) * kTile;
+      typedef std::true_type Y;
+      typedef std::false_type N;
+      if (cur_live && t <= t_last) {
+        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {   // tile t - 1's P V is complete, tile t not yet exponentiated
+          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+          l2 *= (f32x2_t){alpha, alpha};
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+        }
+        m = m_new;
+        float mx = -INFINITY;
+        if (next_live && !next_edge) {
+          phase1(Y{}, kn, c0, c1, n0, n1, m_new);
+          phase2(Y{}, vc, c0, c1, n0, n1, mx);
+          m_new = fmaxf(m, finish_max(mx));
+        } else if (next_live) {
+          phase1(Y{}, kn, c0, c1, n0, n1, m_new);
+          phase2(N{}, vc, c0, c1, n0, n1, mx);
+          apply_mask(t + 1, vw_next, n0, n1);
+          m_new = fmaxf(m, finish_max(row_max(n0, n1)));
+        } else {
+          phase1(N{}, kn, c0, c1, n0, n1, m_new);
+          phase2(N{}, vc, c0, c1, n0, n1, mx);
+        }
+      } else if (next_live) {   // tile t added nothing for this wave (padding) but tile t + 1 does
+        s_plain(kn, n0, n1);
+        if (next_edge) apply_mask(t + 1, vw_next, n0, n1);
+        m_new = fmaxf(m, finish_max(row_max(n0, n1)));
+      }
+      cur_live = next_live;
+    };
+    for (int t = 0; t < nt; t += 2) {
+      tile(t, sa0, sa1, sb0, sb1);
+      if (t + 1 < nt) tile(t + 1, sb0, sb1, sa0, sa1);
+    }
+    const float l = l2[0] + l2[1];
+    const float l_tot = l + __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l_tot;
+    bf16_t* orow = out + (int64_t)b * p.q_sb + (int64_t)qi * p.q_ss + (int64_t)h * p.q_sh;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        bf16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(acc[d][4 * qd + e] * inv);
+        *reinterpret_cast<bf16x4_t*>(orow + d * 32 + 8 * qd + 4 * g) = o;
+      }
+    if (g == 0) lse_out[((int64_t)b * p.H + h) * p.S + qi] = (m + __builtin_amdgcn_logf(l_tot)) * (1.0f / LOG2E);
+  }  // rep
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+}  // namespace
+
+int launch_flash_fwd2(const FlashParams& p, bf16_t* out, float* lse, bool causal, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    bool ok = true;
+#define FWD2_ATTR(C_, M_)                                                                              \
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd2_kernel<C_, M_>),             \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSmemFwd) == hipSuccess
+    FWD2_ATTR(true, true); FWD2_ATTR(true, false); FWD2_ATTR(false, false);
+#undef FWD2_ATTR
+    if (!ok) return CMB_ERR_LAUNCH;
+    attr_done = true;
+  }
+  const int64_t nqb = p.S / 128;
+  const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal) * p.H * p.B));   // 1-D: flash_map.h
+  if (causal && p.key_valid) hipLaunchKernelGGL((flash_fwd2_kernel<true, true>), grid, dim3(256), kSmemFwd, stream, p, out, lse);
+  else if (causal) hipLaunchKernelGGL((flash_fwd2_kernel<true, false>), grid, dim3(256), kSmemFwd, stream, p, out, lse);
+  else hipLaunchKernelGGL((flash_fwd2_kernel<false, false>), grid, dim3(256), kSmemFwd, stream, p, out, lse);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+}  // namespace cmb_flash

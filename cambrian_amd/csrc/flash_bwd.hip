@@ -15,49 +15,11 @@
 // accumulated, results are bit-reproducible.
 // Layout: all of q, k, v, o, do, dq, dk, dv are addressed as [B, S, H, 128] through (batch, token, head) element strides
 // (token-major storage, what ops.qkv_rope produces and the attention returns); lse / D are fp32 [B, H, S].
-#include "common.h"
-#include "flash_map.h"
+#include "flash_common.h"
+
+using namespace cmb_flash;
 
 namespace {
-
-constexpr int HD = 128;       // head dim
-constexpr int KS = HD / 16;   // MFMA k-steps over the head dim
-constexpr int DT = HD / 32;   // 32-wide d tiles
-constexpr int LDR = HD + 8;   // row-major LDS tile row stride (elements): conflict-free ds_read_b128
-constexpr int LDT = 68;       // transposed LDS tile row stride (elements): conflict-free ds_read_b64
-constexpr float LOG2E = 1.4426950408889634f;
-
-struct FlashParams {
-  const bf16_t *q, *k, *v, *o, *dout;
-  bf16_t *dq, *dk, *dv;
-  const float* lse;  // [B, H, S]
-  float* dvec;       // [B, H, S]  D = rowsum(dO * O)
-  int64_t q_sb, q_ss, q_sh;     // strides of q / o / do / dq (elements)
-  int64_t kv_sb, kv_ss, kv_sh;  // strides of k / v / dk / dv
-  int B, S, H, HKV;
-  int kv_len;   // non-causal kernels: keys >= kv_len are padding (masked); S is kv_len rounded up to 128
-  float scale;
-  // causal kernels: optional key-padding mask, [B, S] bytes, non-zero = the key may be attended to.  A query may see key k
-  // iff k <= q and (key_valid[b][k] or k == q): the collator's attention_mask (train_fsdp.py:1057-1085) AND the causal
-  // triangle, with the diagonal kept open so that a padded query row is never empty (its loss is ignored).
-  const uint8_t* key_valid;
-};
-
-// validity bits of the 64 keys of tile t (lane i contributes key 64 t + i); all ones without a mask
-__device__ __forceinline__ uint8_t kv_byte(const FlashParams& p, int b, int t, int lane) {
-  return p.key_valid ? p.key_valid[(int64_t)b * p.S + t * 64 + lane] : (uint8_t)1;
-}
-
-// Which of this lane's 16 keys of one 32-key half tile are open to its query: bit (r & 3) + 8 (r >> 2) <-> accumulator
-// element r (key = half tile base + 4 g + that bit index).  `vw` is the tile's 64-bit key-validity ballot; `dq` = the
-// lane's query index minus the half tile's first key: the query's own key stays open even when it is padding (the
-// diagonal of the collator mask, train_fsdp.py:1057-1085) — folded into the word here so that the per-element test is
-// one constant-bit test.
-__device__ __forceinline__ uint32_t flash_open_bits(uint64_t vw, int kt, int g, int dq) {
-  const uint32_t w = (uint32_t)(vw >> (kt * 32)) >> (4 * g);
-  const uint32_t pos = (uint32_t)(dq - 4 * g);  // bit of the query's own key in w (if < 32 and in this lane's groups)
-  return w | ((pos < 32u && !(pos & 4u)) ? (1u << pos) : 0u);
-}
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -938,17 +900,15 @@ extern "C" int cmb_flash_attn_fwd(const void* q, const void* k, const void* v, i
   p.B = (int)B; p.S = (int)S; p.H = H; p.HKV = HKV; p.scale = scale; p.kv_len = causal ? (int)S : (int)kv_len;
   p.key_valid = causal ? key_valid : nullptr;
   const int64_t nqb = S / 128;
+  // knob bit 0: the round-5 forward on LDS-DMA tiles (flash2.hip); else the round-4 kernel
+  if ((cmb_knob(CMB_KNOB_FLASH) & 1) != 0) return launch_flash_fwd2(p, (bf16_t*)out, lse, causal != 0, (hipStream_t)stream);
   const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal != 0) * H * B));   // 1-D: flash_map.h
-  const bool pipe = (cmb_knob(CMB_KNOB_FLASH) & 1) != 0;   // bit 0 (default on): fragment reads run ahead of the MFMAs
-#define FLASH_FWD_LAUNCH(C_, M_)                                                                                          \
-  do {                                                                                                                    \
-    if (pipe) hipLaunchKernelGGL((flash_fwd_kernel<C_, M_, true>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse); \
-    else hipLaunchKernelGGL((flash_fwd_kernel<C_, M_, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);    \
-  } while (0)
-  if (causal && p.key_valid) FLASH_FWD_LAUNCH(true, true);
-  else if (causal) FLASH_FWD_LAUNCH(true, false);
-  else FLASH_FWD_LAUNCH(false, false);
-#undef FLASH_FWD_LAUNCH
+  if (causal && p.key_valid)
+    hipLaunchKernelGGL((flash_fwd_kernel<true, true, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
+  else if (causal)
+    hipLaunchKernelGGL((flash_fwd_kernel<true, false, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
+  else
+    hipLaunchKernelGGL((flash_fwd_kernel<false, false, false>), grid, dim3(256), 0, (hipStream_t)stream, p, (bf16_t*)out, lse);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

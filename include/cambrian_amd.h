@@ -82,12 +82,13 @@ int cmb_abi_version(void);
  *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
  *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
  *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 7 (one wave per SIMD) or 4 (two)
- *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask (default 7): 1 = forward, 2 = dQ, 4 = dK/dV kernel takes the round-5
+ *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask (default 4: the dK/dV kernel only — the forward measured neutral
+ *                       and the one-workgroup-per-CU dQ variant slower, profiles/r05_lab.md): 1 = forward, 2 = dQ, 4 = dK/dV kernel takes the round-5
  *                       tile body (LDS fragment reads a ring of four ahead of the MFMAs in a fixed order; dQ / dK/dV: the other
  *                       half tile's exponentials issued between the MFMAs); 0 = the round-4 kernels.  Bit-identical results */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
                    CMB_KNOB_FLASH = 5, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 7, 0, 0
+#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 4, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 
