@@ -6,16 +6,14 @@
 //     XOR-swizzled on the source side (flash_layout.h): no tile registers, no 16-bit shuffles, no ds_write — the round-4
 //     kernel spent ~80 of its ~230 vector instructions per tile and wave packing the transposed V image and 32 registers on
 //     the tile in flight.  V is consumed straight from the row-major image with transposing reads (ds_read_b64_tr_b16);
-//   * two K and two V buffers, ONE barrier per tile (the round-4 kernel: two): top of iteration t = "my pieces of K(t+1),
-//     V(t) have landed" (s_waitcnt vmcnt(0)) + barrier, then the DMA of K(t+2), V(t+1) goes out and flies for a whole tile;
-//   * the wave's two score sets: while the matrix pipe runs S(t+1) = K(t+1) Q^T the vector pipes exponentiate tile t, and
-//     while it runs O += V(t) P(t) they take the row maximum of tile t+1 — every MFMA is followed, in a FIXED order
-//     (FL_FENCE), by the LDS read of the fragment four products ahead and by its share of the other tile's softmax (<= 5
-//     instructions per MFMA, MI355X_MICROARCH.md: one wave hides about five single-issue instructions behind a 32 x 32 x 16
-//     MFMA).  The rescale decision of tile t+1 is taken after tile t's P V has completed and before tile t+1 is
-//     exponentiated (the safe order of cdna_hip_programming.md T13);
+//   * two K and two V buffers, ONE barrier per tile (the round-4 kernel: two): top of iteration t = "my pieces of K(t), V(t)
+//     have landed" (s_waitcnt vmcnt(0)) + barrier, then the DMA of tile t + 1 goes out and flies for the whole tile;
+//   * the LDS fragment reads of both products run a ring of four fragments ahead of the MFMAs in a fixed order (FL_FENCE);
 //   * packed fp32 arithmetic for the exponent argument and the row sum (two partial sums per lane).
-// Tiles that need a mask (the wave's diagonal tiles, padded keys) take mask + maximum after the P V phase, un-overlapped.
+// Two workgroups per CU as before (the other workgroup's waves fill a wave's softmax phase).  Variants measured on the way
+// (profiles/r05_lab.md): two score sets per wave with the next tile's S product issued beside this tile's exponentials — 256
+// registers do not hold them (289 spills), one workgroup per CU with 386-512 registers ran 578 TFLOP/s against the round-4
+// kernel's 715: hipcc moved the score sets between the register halves ~100 times per tile; 64-query waves: 512 registers + spills.
 // Results agree with flash_fwd_kernel to fp32 rounding (the row sum is accumulated in two partial sums here), not bit for
 // bit; tests/test_flash_bwd_gpu.py holds both against fp32 autograd of the plain formula.
 #include <type_traits>
@@ -54,7 +52,7 @@ __device__ __forceinline__ void dma_piece(const char* base, uint32_t voff, uint3
 }
 
 template <bool CAUSAL, bool MASKED>
-__global__ void __launch_bounds__(256, 1) flash_fwd2_kernel(const FlashParams p, bf16_t* __restrict__ out,
+__global__ void __launch_bounds__(256, 2) flash_fwd2_kernel(const FlashParams p, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse_out) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -174,47 +172,28 @@ __global__ void __launch_bounds__(256, 1) flash_fwd2_kernel(const FlashParams p,
         FL_FENCE();
       }
     };
-    // element pair (e, e + 1) of the current tile's scores -> probabilities (in place), row sum
-    auto exp_pair = [&](f32x16_t& s0, f32x16_t& s1, int e, f32x2_t nm2, f32x2_t c22) __attribute__((always_inline)) {
-      f32x16_t& s = (e < 16) ? s0 : s1;
-      const int r = e & 15;
-      const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s[r], s[r + 1]}, c22, nm2);
-      const f32x2_t pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-      l2 += pv;
-      s[r] = pv[0];
-      s[r + 1] = pv[1];
-    };
-    // Phase 1: [S of the next tile] beside the exponentials of the current one
-    auto phase1 = [&](auto next_c, const char* kbuf, f32x16_t& c0, f32x16_t& c1, f32x16_t& n0, f32x16_t& n1, float m_new)
-        __attribute__((always_inline)) {
-      constexpr bool NEXT = decltype(next_c)::value;
+    // the tile's probabilities (in place) and row sum: packed exponent arguments, two partial sums per lane
+    auto exp_all = [&](f32x16_t& s0, f32x16_t& s1, float m_new) __attribute__((always_inline)) {
       const f32x2_t nm2 = {-m_new, -m_new}, c22 = {c2, c2};
-      bf16x8_t kr[4];
-      if (NEXT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) kr[i] = kfrag(kbuf, i);
-      }
-      FL_FENCE();
-#pragma unroll
-      for (int i = 0; i < 2 * KS; ++i) {
-        if (NEXT) {
-          if (i < 2) (i ? n1 : n0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[0], (f32x16_t){0}, 0, 0, 0);
-          else (i & 1 ? n1 : n0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[i >> 1], (i & 1 ? n1 : n0), 0, 0, 0);
-          if (i + 4 < 2 * KS) kr[i & 3] = kfrag(kbuf, i + 4);
-        }
-        exp_pair(c0, c1, 2 * i, nm2, c22);
-        FL_FENCE();
+      for (int e = 0; e < 32; e += 2) {
+        f32x16_t& s = (e < 16) ? s0 : s1;
+        const int r = e & 15;
+        const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s[r], s[r + 1]}, c22, nm2);
+        const f32x2_t pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        l2 += pv;
+        s[r] = pv[0];
+        s[r + 1] = pv[1];
       }
     };
-    // Phase 2: O += V P of the current tile beside [the row maximum of the next one]
-    auto phase2 = [&](auto max_c, const char* vbuf, const f32x16_t& c0, const f32x16_t& c1, const f32x16_t& n0,
-                      const f32x16_t& n1, float& mx) __attribute__((always_inline)) {
-      constexpr bool MAXN = decltype(max_c)::value;
+    // O += V P: V fragments by transposing reads, a ring of four ahead of the MFMAs
+    auto pv_product = [&](const char* vbuf, const f32x16_t& c0, const f32x16_t& c1) __attribute__((always_inline)) {
       auto pel = [&](int e) -> float { return e < 16 ? c0[e] : c1[e - 16]; };
-      auto nel = [&](int e) -> float { return e < 16 ? n0[e] : n1[e - 16]; };
       u32x4_v pf[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pf[0][c] = cvt2(pel(2 * c), pel(2 * c + 1));
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pf[kb][c] = cvt2(pel(8 * kb + 2 * c), pel(8 * kb + 2 * c + 1));
       s16x4_t vlo[4], vhi[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -232,85 +211,43 @@ __global__ void __launch_bounds__(256, 1) flash_fwd2_kernel(const FlashParams p,
           vlo[i & 3] = vfrag_half(vbuf, i + 4, 0);
           vhi[i & 3] = vfrag_half(vbuf, i + 4, 1);
         }
-        if (i < 12) {   // the operand of the NEXT key block: elements 8 (kb + 1) + 2 c, + 1 with c = i & 3
-          const int e = 8 * ((i >> 2) + 1) + 2 * (i & 3);
-          pf[(i >> 2) + 1][i & 3] = cvt2(pel(e), pel(e + 1));
-        }
-        if (MAXN) mx = fmaxf(fmaxf(mx, nel(2 * i)), nel(2 * i + 1));
         FL_FENCE();
       }
     };
 
-    // ---- prologue: K(0), V(0), K(1) in flight; S(0) and its maximum
+    // ---- prologue: K(0), V(0) in flight
     uint8_t vb = MASKED ? kv_byte(p, b, 0, lane) : (uint8_t)1;
     __syncthreads();                    // the previous rep is done with every buffer
     issue_k(0);
     issue_v(0);
-    if (nt > 1) issue_k(1);
-    uint64_t vw_cur = MASKED ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
-    if (MASKED && nt > 1) vb = kv_byte(p, b, 1, lane);
-    if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K(0), V(0) landed (K(1)'s four pieces may fly on)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    f32x16_t sa0, sa1, sb0, sb1;   // two score sets (A = even tiles, B = odd tiles)
-    s_plain(smem, sa0, sa1);
-    if (edge_tile(0, vw_cur)) apply_mask(0, vw_cur, sa0, sa1);
-    float m_new = fmaxf(m, finish_max(row_max(sa0, sa1)));
-    bool cur_live = !(MASKED && vw_cur == 0 && 63 < q0);   // (a tile of padding below the diagonal adds nothing)
-
-    // one tile: (c0, c1) hold the scores of tile t, (n0, n1) receive those of tile t + 1
-    auto tile = [&](int t, f32x16_t& c0, f32x16_t& c1, f32x16_t& n0, f32x16_t& n1) __attribute__((always_inline)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of K(t + 1), V(t) have landed
-      __syncthreads();                                   // everybody's have; everybody is done with K(t), V(t - 1)
-      if (t + 2 < nt) issue_k(t + 2);
-      uint64_t vw_next = ~0ull;
-      if (t + 1 < nt) {
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of K(t), V(t) have landed
+      __syncthreads();                                   // everybody's have; everybody is done with K(t - 1), V(t - 1)
+      const uint64_t vw = MASKED ? __builtin_amdgcn_ballot_w64(vb != 0) : ~0ull;
+      if (t + 1 < nt) {                                  // the next tile flies during this tile's products
+        issue_k(t + 1);
         issue_v(t + 1);
-        if (MASKED) {
-          vw_next = __builtin_amdgcn_ballot_w64(vb != 0);
-          if (t + 2 < nt) vb = kv_byte(p, b, t + 2, lane);
-        }
+        if (MASKED) vb = kv_byte(p, b, t + 1, lane);
       }
-      const bool next_live = (t + 1 <= t_last && t + 1 < nt) && !(MASKED && vw_next == 0 && (t + 1) * 64 + 63 < q0);
-      const bool next_edge = next_live && edge_tile(t + 1, vw_next);
-      const char* kn = smem + ((t + 1) & 1) * kTile;
+      if (t > t_last) continue;                                   // whole tile above this wave's diagonal
+      if (MASKED && vw == 0 && t * 64 + 63 < q0) continue;        // a tile of padding below the diagonal: nothing to add
+      const char* kc = smem + (t & 1) * kTile;
       const char* vc = smem + 2 * kTile + (t & 1) * kTile;
-      typedef std::true_type Y;
-      typedef std::false_type N;
-      if (cur_live && t <= t_last) {
-        if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {   // tile t - 1's P V is complete, tile t not yet exponentiated
-          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-          l2 *= (f32x2_t){alpha, alpha};
+      f32x16_t s0, s1;
+      s_plain(kc, s0, s1);
+      if (edge_tile(t, vw)) apply_mask(t, vw, s0, s1);
+      const float m_new = fmaxf(m, finish_max(row_max(s0, s1)));
+      if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        l2 *= (f32x2_t){alpha, alpha};
 #pragma unroll
-          for (int d = 0; d < DT; ++d)
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
-        }
-        m = m_new;
-        float mx = -INFINITY;
-        if (next_live && !next_edge) {
-          phase1(Y{}, kn, c0, c1, n0, n1, m_new);
-          phase2(Y{}, vc, c0, c1, n0, n1, mx);
-          m_new = fmaxf(m, finish_max(mx));
-        } else if (next_live) {
-          phase1(Y{}, kn, c0, c1, n0, n1, m_new);
-          phase2(N{}, vc, c0, c1, n0, n1, mx);
-          apply_mask(t + 1, vw_next, n0, n1);
-          m_new = fmaxf(m, finish_max(row_max(n0, n1)));
-        } else {
-          phase1(N{}, kn, c0, c1, n0, n1, m_new);
-          phase2(N{}, vc, c0, c1, n0, n1, mx);
-        }
-      } else if (next_live) {   // tile t added nothing for this wave (padding) but tile t + 1 does
-        s_plain(kn, n0, n1);
-        if (next_edge) apply_mask(t + 1, vw_next, n0, n1);
-        m_new = fmaxf(m, finish_max(row_max(n0, n1)));
+          for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
       }
-      cur_live = next_live;
-    };
-    for (int t = 0; t < nt; t += 2) {
-      tile(t, sa0, sa1, sb0, sb1);
-      if (t + 1 < nt) tile(t + 1, sb0, sb1, sa0, sa1);
+      m = m_new;
+      exp_all(s0, s1, m_new);
+      pv_product(vc, s0, s1);
     }
     const float l = l2[0] + l2[1];
     const float l_tot = l + __shfl_xor(l, 32, 64);
