@@ -9,7 +9,9 @@
 //   * two K and two V buffers, ONE barrier per tile (the round-4 kernel: two): top of iteration t = "my pieces of K(t), V(t)
 //     have landed" (s_waitcnt vmcnt(0)) + barrier, then the DMA of tile t + 1 goes out and flies for the whole tile;
 //   * the LDS fragment reads of both products run a ring of four fragments ahead of the MFMAs in a fixed order (FL_FENCE);
-//   * packed fp32 arithmetic for the exponent argument and the row sum (two partial sums per lane).
+//   * the exponentials sit INSIDE the P V phase: key block kb's eight probabilities are computed and converted while the four
+//     MFMAs of key block kb - 1 run (five vector instructions per MFMA), packed fp32 for the exponent argument and the row sum
+//     (two partial sums per lane); only the row maximum and the first key block's exponentials run with the matrix pipe idle.
 // Two workgroups per CU as before (the other workgroup's waves fill a wave's softmax phase).  Variants measured on the way
 // (profiles/r05_lab.md): two score sets per wave with the next tile's S product issued beside this tile's exponentials — 256
 // registers do not hold them (289 spills), one workgroup per CU with 386-512 registers ran 578 TFLOP/s against the round-4
@@ -172,33 +174,34 @@ __global__ void __launch_bounds__(256, 2) flash_fwd2_kernel(const FlashParams p,
         FL_FENCE();
       }
     };
-    // the tile's probabilities (in place) and row sum: packed exponent arguments, two partial sums per lane
-    auto exp_all = [&](f32x16_t& s0, f32x16_t& s1, float m_new) __attribute__((always_inline)) {
-      const f32x2_t nm2 = {-m_new, -m_new}, c22 = {c2, c2};
-#pragma unroll
-      for (int e = 0; e < 32; e += 2) {
-        f32x16_t& s = (e < 16) ? s0 : s1;
-        const int r = e & 15;
-        const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s[r], s[r + 1]}, c22, nm2);
-        const f32x2_t pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-        l2 += pv;
-        s[r] = pv[0];
-        s[r + 1] = pv[1];
-      }
+    // probabilities of elements (e, e + 1) (in place) and their share of the row sum: packed exponent argument, two partial sums
+    auto exp_pair = [&](f32x16_t& s0, f32x16_t& s1, int e, f32x2_t nm2, f32x2_t c22) __attribute__((always_inline)) {
+      f32x16_t& s = (e < 16) ? s0 : s1;
+      const int r = e & 15;
+      const f32x2_t t = __builtin_elementwise_fma((f32x2_t){s[r], s[r + 1]}, c22, nm2);
+      const f32x2_t pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+      l2 += pv;
+      s[r] = pv[0];
+      s[r + 1] = pv[1];
     };
-    // O += V P: V fragments by transposing reads, a ring of four ahead of the MFMAs
-    auto pv_product = [&](const char* vbuf, const f32x16_t& c0, const f32x16_t& c1) __attribute__((always_inline)) {
+    // O += V P with the exponentials inside it: the operand of key block kb (elements 8 kb .. 8 kb + 7) is exponentiated and
+    // converted while the four MFMAs of key block kb - 1 run (one element pair per MFMA: pk_fma, 2 exp, pk_add, cvt — the five
+    // instructions an MFMA hides); only key block 0's eight exponentials run in front of the first MFMA.  V fragments by
+    // transposing reads, a ring of four ahead of the MFMAs.
+    auto exp_pv = [&](const char* vbuf, f32x16_t& c0, f32x16_t& c1, float m_new) __attribute__((always_inline)) {
+      const f32x2_t nm2 = {-m_new, -m_new}, c22 = {c2, c2};
       auto pel = [&](int e) -> float { return e < 16 ? c0[e] : c1[e - 16]; };
-      u32x4_v pf[4];
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) pf[kb][c] = cvt2(pel(8 * kb + 2 * c), pel(8 * kb + 2 * c + 1));
+      u32x4_v pf[2];
       s16x4_t vlo[4], vhi[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         vlo[i] = vfrag_half(vbuf, i, 0);
         vhi[i] = vfrag_half(vbuf, i, 1);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        exp_pair(c0, c1, 2 * c, nm2, c22);
+        pf[0][c] = cvt2(pel(2 * c), pel(2 * c + 1));
       }
       FL_FENCE();
 #pragma unroll
@@ -206,10 +209,15 @@ __global__ void __launch_bounds__(256, 2) flash_fwd2_kernel(const FlashParams p,
         const s16x8_t vv = {vlo[i & 3][0], vlo[i & 3][1], vlo[i & 3][2], vlo[i & 3][3],
                             vhi[i & 3][0], vhi[i & 3][1], vhi[i & 3][2], vhi[i & 3][3]};
         acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv),
-                                                              __builtin_bit_cast(bf16x8_t, pf[i >> 2]), acc[i & 3], 0, 0, 0);
+                                                              __builtin_bit_cast(bf16x8_t, pf[(i >> 2) & 1]), acc[i & 3], 0, 0, 0);
         if (i + 4 < 4 * DT) {
           vlo[i & 3] = vfrag_half(vbuf, i + 4, 0);
           vhi[i & 3] = vfrag_half(vbuf, i + 4, 1);
+        }
+        if (i < 12) {   // component c = i & 3 of the NEXT key block's operand: elements 8 (kb + 1) + 2 c, + 1
+          const int e = 8 * ((i >> 2) + 1) + 2 * (i & 3);
+          exp_pair(c0, c1, e, nm2, c22);
+          pf[((i >> 2) + 1) & 1][i & 3] = cvt2(pel(e), pel(e + 1));
         }
         FL_FENCE();
       }
@@ -246,8 +254,7 @@ __global__ void __launch_bounds__(256, 2) flash_fwd2_kernel(const FlashParams p,
           for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
       }
       m = m_new;
-      exp_all(s0, s1, m_new);
-      pv_product(vc, s0, s1);
+      exp_pv(vc, s0, s1, m_new);
     }
     const float l = l2[0] + l2[1];
     const float l_tot = l + __shfl_xor(l, 32, 64);

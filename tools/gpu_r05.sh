@@ -36,7 +36,17 @@ P
       else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15; fi
       python __graft_entry__.py smoke 2>&1 | tail -2
       ;;
-    lab) timeout 1200 python tools/r05_lab.py "$@" 2>&1 | tail -60 ;;
+    lab) timeout 300 python tools/r05_lab.py "$@" 2>&1 | tail -60 ;;
+    pmcflash)   # SQ counter passes (separate --pmc runs, --kernel-trace only) of the flash kernels: pmcflash <knob> <fwd|bwd> <kernel substring...>
+      local knob=$1 what=$2; shift 2
+      local W=flashonly; [ "$what" == "bwd" ] && W=flashbwdonly
+      local P=$GRAFT_REPO_ROOT/$O/pmc_$TAG; mkdir -p $P
+      local CMD="python $GRAFT_REPO_ROOT/tools/r05_lab.py $W --knob $knob --B 8"
+      ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $P/sq -o sq -- $CMD > $P/sq.log 2>&1
+        timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $P/sq2 -o sq2 -- $CMD > $P/sq2.log 2>&1 )
+      for k in "$@"; do python tools/pmc_sq_summarise.py $P $k | tee -a $O/pmc_flash_$TAG.jsonl | cut -c1-1500; done
+      rm -rf $P
+      ;;
     py) timeout 1200 python "$@" 2>&1 | tail -60 ;;
     *) echo "unknown verb $verb"; return 2 ;;
   esac

@@ -106,11 +106,32 @@ def flash_case(B, S=2048, H=32, HKV=8, masked=False, causal=True):
           "bwd_TFLOPs_effective_2.5x": {k_: round(2.5 * fl / t[k_] / 1e6, 1) for k_ in ("bwd_old", "bwd_new")}})
 
 
+def flash_only(B, knob, iters=3, what="fwd"):
+    """a few launches of one flash kernel variant (the workload of the rocprofv3 --pmc passes: tools/gpu_r05.sh pmcflash)"""
+    D, S, H, HKV = 128, 2048, 32, 8
+    g = torch.Generator(device=dev).manual_seed(1)
+    q = torch.randn((B, S, H, D), device=dev, dtype=torch.bfloat16, generator=g).transpose(1, 2).requires_grad_()
+    k = torch.randn((B, S, HKV, D), device=dev, dtype=torch.bfloat16, generator=g).transpose(1, 2).requires_grad_()
+    v = torch.randn((B, S, HKV, D), device=dev, dtype=torch.bfloat16, generator=g).transpose(1, 2).requires_grad_()
+    do = torch.randn((B, S, H, D), device=dev, dtype=torch.bfloat16, generator=g).transpose(1, 2)
+    L.knob_set(L.KNOB_FLASH, knob)
+    for _ in range(iters):
+        o = ops.CausalAttnFn.apply(q, k, v, None, None, None)
+        if what == "bwd":
+            torch.autograd.grad(o, (q, k, v), do)
+    torch.cuda.synchronize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="+")
     ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--knob", type=int, default=0)
     a = ap.parse_args()
+    if "flashonly" in a.what:
+        flash_only(a.B, a.knob, what="fwd")
+    if "flashbwdonly" in a.what:
+        flash_only(a.B, a.knob, what="bwd")
     if "flash" in a.what or "all" in a.what:
         flash_case(a.B)
         flash_case(a.B, masked=True)
