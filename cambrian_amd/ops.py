@@ -1702,7 +1702,7 @@ class CausalAttnFn(torch.autograd.Function):
         dq = torch.empty((B, S, H, D), dtype=q.dtype, device=q.device)
         dk = torch.empty((B, S, HKV, D), dtype=q.dtype, device=q.device)
         dv = torch.empty((B, S, HKV, D), dtype=q.dtype, device=q.device)
-        dvec = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+        dvec = torch.empty((2, B, H, S), dtype=torch.float32, device=q.device)   # [0] D, [1] lse * log2 e (flash2.hip)
         lse = lse.contiguous()
         rc = L.load().cmb_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                          lse.data_ptr(), B, S, H, HKV, D, S * H * D, H * D, D, S * HKV * D, HKV * D, D,

@@ -66,7 +66,7 @@ const char* cmb_version(void);
  * the kernel-selection knobs of round 4 = 5).  Bindings must compare it with the revision they
  * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
  * library still resolves, and a shifted argument list corrupts memory instead of failing. */
-#define CMB_ABI_VERSION 5
+#define CMB_ABI_VERSION 6
 int cmb_abi_version(void);
 
 /* Run-time kernel-selection knobs: which of several kernels that compute the SAME function an entry point launches
@@ -82,13 +82,12 @@ int cmb_abi_version(void);
  *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
  *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
  *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 7 (one wave per SIMD) or 4 (two)
- *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask (default 4: the dK/dV kernel only — the forward measured neutral
- *                       and the one-workgroup-per-CU dQ variant slower, profiles/r05_lab.md): 1 = forward, 2 = dQ, 4 = dK/dV kernel takes the round-5
- *                       tile body (LDS fragment reads a ring of four ahead of the MFMAs in a fixed order; dQ / dK/dV: the other
- *                       half tile's exponentials issued between the MFMAs); 0 = the round-4 kernels.  Bit-identical results */
+ *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask: 1 = forward, 2 = dQ, 8 = dK/dV on LDS-DMA operand tiles with transposing
+ *                       reads (flash2.hip; 8 needs 2); 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 0 = the
+ *                       round-4 kernels.  dQ / dK / dV are bit-identical across variants, the forward to fp32 rounding */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
                    CMB_KNOB_FLASH = 5, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 4, 0, 0
+#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 15, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 
@@ -466,7 +465,8 @@ int cmb_qkv_rope(int dtype, int32_t merge, void* packed, const float* cos_t, con
 /* Backward of causal self-attention with grouped KV heads (the decoder's F.scaled_dot_product_attention(is_causal=True,
  * enable_gqa=True); HF LlamaAttention reached from cambrian_llama.py:157-166).  bf16, head_dim 128, S % 128 == 0.
  * q / o / dout / dq are [B,S,H,128] and k / v / dk / dv [B,S,HKV,128] through (batch, token, head) element strides;
- * lse fp32 [B,H,S] = log sum_j exp(scale * q.k_j) from the forward; dvec fp32 [B,H,S] is scratch (receives rowsum(dO*O)).
+ * lse fp32 [B,H,S] = log sum_j exp(scale * q.k_j) from the forward; dvec fp32 [2,B,H,S] is scratch (ABI 6: [0] receives rowsum(dO*O), [1] lse * log2 e for the
+ * LDS-DMA dK/dV kernel).
  * Two MFMA kernels (dQ; dK+dV), no atomics, bit-reproducible. */
 /* Forward of the same attention: out [B,S,H,128] (strides of q), lse fp32 [B,H,S].
  * causal == 0 is the bidirectional form used when the vision towers train (HF CLIPAttention /
