@@ -45,7 +45,8 @@ def test_absorbed_equals_direct(T, nsmall):
 
 def test_absorbed_tower_selection(monkeypatch):
     """VisionCrossAttentionLayer._absorbed_tower: which configuration takes the absorbed path — bf16 or fp32, 1024-wide features,
-    exactly one windowed tower (up to 4 x 4) beside at most four one-key towers, fp8 projections off, switch on."""
+    exactly one windowed tower (up to 4 x 4) beside at most four one-key towers, switch on; ``config.fp8_projections`` composes with it
+    (round 5: the fp8 GEMMs are the per-token ones that remain)."""
     import cambrian_amd.model.vision_sampler as VS
     from cambrian_amd import ops
 
@@ -65,7 +66,7 @@ def test_absorbed_tower_selection(monkeypatch):
     assert layer([1, 8])._absorbed_tower(q16, feats([1, 8])) == -1                # window larger than 4 x 4
     assert layer([1] * 5 + [4])._absorbed_tower(q16, feats([1] * 5 + [4])) == -1  # more than four one-key towers
     monkeypatch.setattr(ops, "_FP8_LINEAR", True, raising=False)
-    assert layer(rel)._absorbed_tower(q16, feats(rel)) == -1                      # config.fp8_projections
+    assert layer(rel)._absorbed_tower(q16, feats(rel)) == 3                       # config.fp8_projections no longer switches it off
     monkeypatch.setattr(ops, "_FP8_LINEAR", False, raising=False)
     monkeypatch.setattr(VS, "ABSORB_KV", False)
     assert layer(rel)._absorbed_tower(q16, feats(rel)) == -1                      # CAMBRIAN_AMD_ABSORB_KV=0
