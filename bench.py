@@ -358,7 +358,15 @@ PARITY = {
                  "lines + installed-HF towers and decoder layers cast to bf16, same geometry and batch, build container)",
         "logits_max_rel": 3.5e-2, "logits_l2": 2.6e-2, "logits_slope_err": 4.5e-4, "grad_tensor_median_max_rel": 3.3e-2,
         "worst_grad_tensor_max_rel": 4.9e-1,
-        "assertion": "every HIP bf16 figure <= 1.5 x its reference-bf16 twin (test_release_width_gpu.py)"},
+        "assertion": "logits (max / L2 / slope) and the median / p90 gradient tensor <= 1.5 x their reference-bf16 twins; for the WORST "
+                     "gradient tensor the twin (0.49) is no yardstick — the absolute 8e-2 binds (test_release_width_gpu.py)"},
+    "full_depth_bf16_vs_fp32_hip": {
+        "where": "tools/full_depth_parity.py -> profiles/r05_parity_observed.jsonl: the HIP path in bf16 against ITS OWN fp32 instantiation "
+                 "(pinned to the CPU oracle at 1.2e-5) at the FULL release depth — 32 decoder layers, 3 + 10 SVA layers, full-depth "
+                 "towers, vocabulary 128256, collator batch of 2 letter-boxed images, same weights (decoder rounded to bf16)",
+        "logits_max_rel": 1.01e-1, "logits_rel_l2": 6.6e-2, "logits_slope_err": 2.2e-3, "loss_fp32": 12.5276, "loss_bf16": 12.5282,
+        "grad_tensor_max_rel_median": 9.3e-2, "grad_tensor_max_rel_p90": 1.36e-1, "grad_tensor_max_rel_worst": 3.6e-1,
+        "note": "4.3 x the 4-layer release-width figure (2.35e-2): rounding noise grows with depth, the slope stays at 1 to 2e-3"},
     "hidden_256_model": {"logits_max_rel": "7.9e-3 .. 9.2e-3 (bound 2e-2)", "worst_grad": "1.5e-2 .. 1.9e-2 (bound 4e-2)",
                          "where": "tests/test_model_gpu.py"},
     "systematic_error_checks": "least-squares slope |s - 1| < 5e-3 (logits) / 2e-2 (gradients), relative L2 (tests/conftest.py::fit_err)",
@@ -646,7 +654,8 @@ def compact_line(full: dict) -> dict:
             "fp32_path_logits_max_rel_release_width": 1.2e-5, "north_star_tolerance": "1e-3 rel: met by the fp32 path only",
             "bf16_logits_max_rel_release_width": p["release_width_vs_fp32_oracle"]["logits_max_rel"]["observed"],
             "reference_own_bf16_logits_max_rel": p["reference_own_bf16_vs_its_fp32"]["logits_max_rel"],
-            "full_depth_bf16_vs_fp32_hip": p.get("full_depth_bf16_vs_fp32_hip"),
+            "full_depth_bf16_vs_fp32_hip_logits_max_rel": (p.get("full_depth_bf16_vs_fp32_hip") or {}).get("logits_max_rel"),
+            "full_depth_bf16_vs_fp32_hip_logits_l2": (p.get("full_depth_bf16_vs_fp32_hip") or {}).get("logits_rel_l2"),
             "where": "tests/test_release_width_gpu.py, tests/test_full_depth_gpu.py, tests/golden/ref_bf16_twin_release_width.json; "
                      "details: --verbose-line / DESIGN.md §3"}
     if "cpu_baseline" in full:

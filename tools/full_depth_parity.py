@@ -32,7 +32,7 @@ def build(dev, dt, llm_layers=None):
     cfg.num_of_vision_sampler_layers = len([k for k in range(10) if 3 * k < depth])
     cfg.start_of_vision_sampler_layers, cfg.stride_of_vision_sampler_layers, cfg.image_position = 0, 3, 91
     torch.manual_seed(0)
-    model = CambrianLlamaForCausalLM(cfg, device=dev, llm_dtype=dt)
+    model = CambrianLlamaForCausalLM(cfg, device=dev, llm_dtype=dt).to(dev)
     for t in model.model.vision_tower_aux_list:
         t._compute_dtype = dt
         t.load_model()
