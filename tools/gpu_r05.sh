@@ -36,6 +36,19 @@ P
       else timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15; fi
       python __graft_entry__.py smoke 2>&1 | tail -2
       ;;
+    modes)   # the NOT_HEADLINE lines: finetune stage with fp32 masters (plain / ZeRO-2 / ZeRO-3 units at world 1), fp8 projections
+      for m in "--stage finetune" "--stage finetune --zero2" "--stage finetune --zero3" "--fp8-projections"; do
+        n=$(echo "$m" | tr -d ' -'); 
+        timeout 600 python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-ab --no-masked-case --no-gemm-pass $m > $O/mode_$n.json 2> $O/mode_$n.err
+        echo "$m rc=$?"; python - <<P
+import json
+try:
+    d=json.loads(open("$O/mode_$n.json").read().strip().splitlines()[-1]); c=d["config"]
+    print(round(d["ms_per_step"],1), "ms", round(d["value"],3), "img/s", "peak", round(c.get("peak_hbm_gb",0),1), "GB", c.get("images_per_gpu"), c.get("optimizer_state"), c.get("NOT_HEADLINE","")[:60])
+except Exception as e: print("parse failed", e); print(open("$O/mode_$n.err").read()[-1500:])
+P
+      done
+      ;;
     lab) timeout 300 python tools/r05_lab.py "$@" 2>&1 | tail -60 ;;
     pmcflash)   # SQ counter passes (separate --pmc runs, --kernel-trace only) of the flash kernels: pmcflash <knob> <fwd|bwd> <kernel substring...>
       local knob=$1 what=$2; shift 2
