@@ -109,6 +109,10 @@ def parse():
     ap.add_argument("--tower-recompute", action="store_true",
                     help="with --unfreeze-towers: per-block activation re-computation inside the four towers")
     ap.add_argument("--bucket-mb", type=float, default=64.0, help="gradient bucket size of GradSync / ZeRO-2 (MiB)")
+    ap.add_argument("--scored-rows", action="store_true",
+                    help="lm_head + cross-entropy only over the scored positions (config.fused_loss = 'scored_rows': shifted label != "
+                         "-100; identical loss and gradients, no logits returned) — NOT the headline line, which computes every row "
+                         "as the reference does")
     ap.add_argument("--verbose-line", action="store_true",
                     help="print the FULL JSON line (20-row calibration table, A/B variants, parity prose, cpu_baseline parts); the "
                          "default line is the compact one (< 8 KB, scalar roofline keys) and the full one is written to "
@@ -712,6 +716,8 @@ def main():
     model, cfg = build_model(dev, args.llm_layers, args.preset, args.unfreeze_towers, args.stage, args.grad_ckpt,
                              args.tower_recompute)
     cfg.fp8_projections = bool(args.fp8_projections)
+    if args.scored_rows:
+        cfg.fused_loss = "scored_rows"
     params = [p for p in model.parameters() if p.requires_grad]
     z3_units = None
     if args.zero3:
@@ -750,7 +756,7 @@ def main():
 
     def make_inputs(nb):
         batch = synthetic_batch(nb, seed=1234 + rank, image_position=pos0)
-        return dict(input_ids=batch["input_ids"].to(dev), labels=batch["labels"].to(dev),
+        return dict(input_ids=batch["input_ids"].to(dev), labels=batch["labels"] if args.scored_rows else batch["labels"].to(dev),
                     position_ids=batch["position_ids"].to(dev),
                     attention_mask=None,  # square synthetic images: nothing is padded -> plain causal attention
                     images=[i.to(dev, torch.bfloat16) for i in batch["images"]],
@@ -882,7 +888,8 @@ def main():
     if not args.no_masked_case:
         sizes = [(336, 224) if i % 2 == 0 else (224, 336) for i in range(B)]
         mb = synthetic_batch(B, seed=4321 + rank, image_position=pos0, image_sizes=sizes)
-        mkw = dict(kw, input_ids=mb["input_ids"].to(dev), labels=mb["labels"].to(dev), position_ids=mb["position_ids"].to(dev),
+        mkw = dict(kw, input_ids=mb["input_ids"].to(dev), labels=mb["labels"] if args.scored_rows else mb["labels"].to(dev),
+                   position_ids=mb["position_ids"].to(dev),
                    attention_mask=mb["attention_mask"].to(dev),
                    image_aux_attention_masks_list=[m_.to(dev) for m_ in mb["image_aux_attention_masks_list"]],
                    image_sizes=mb["image_sizes"])
@@ -924,6 +931,11 @@ def main():
         }
         if batch_fallback:
             line["config"]["batch_fallback"] = batch_fallback
+        if args.scored_rows:
+            scored = int((kw["labels"][:, 1:] != -100).sum())
+            line["config"]["NOT_HEADLINE"] = ("lm_head + cross-entropy over the scored positions only (identical loss / gradients, no "
+                                              "logits returned); the headline line computes every row as the reference does")
+            line["config"]["scored_positions_frac"] = scored / float(kw["labels"].numel())
         if args.fp8_projections:
             line["dtype"] = "bf16 + fp8 (e4m3, row-wise scales) forward GEMMs of the KV-side SVA projections"
             line["config"]["NOT_HEADLINE"] = "reduced-precision mode of BASELINE configs[4]; the headline line is the bf16 run"

@@ -486,6 +486,26 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
             # one context row per query — consumed by the general per-sample hook (cambrian_llama.py:209-253)
             sva = SvaDynamic(sva, _masks, _final_size, _ctx)
         hidden = self.model(inputs_embeds.to(self.model.llm_dtype), position_ids, attention_mask, sva)
+        if labels is not None and getattr(self.config, "fused_loss", False) == "scored_rows":
+            # Opt-in (round 5, ``config.fused_loss = "scored_rows"``): lm_head and the cross-entropy only over the positions that
+            # are scored — shifted label != IGNORE_INDEX; the collator masks the 600 visual slots, the prompt and the padding
+            # (train_fsdp.py:1089-1165), a third of the synthetic batch and more of a real one.  Ignored rows contribute nothing to
+            # the loss and receive a zero gradient, so loss and every gradient are those of the full computation
+            # (tests/test_model_gpu.py::test_scored_rows_loss_equals_the_full_one); what changes is that ``logits`` is not
+            # produced (None) — the reference's training_step reads ``loss`` only (cambrian_trainer.py:226-236).  Labels handed
+            # over on the CPU (as the collator makes them) give the row list without a device synchronisation.
+            Bq_, Sq_, Hd_ = hidden.shape
+            shift_labels = torch.full_like(labels, IGNORE_INDEX)
+            shift_labels[:, :-1] = labels[:, 1:]
+            flat = shift_labels.reshape(-1)
+            idx = torch.nonzero(flat != IGNORE_INDEX).squeeze(1)
+            if idx.numel() > 0:
+                sel = flat[idx].to(hidden.device, non_blocking=True)
+                h_sel = hidden.reshape(Bq_ * Sq_, Hd_).index_select(0, idx.to(hidden.device, non_blocking=True))
+                loss = ops.cross_entropy(_lin(self.lm_head, h_sel), sel, IGNORE_INDEX, inplace=True)
+                if CausalLMOutputWithPast is not None:
+                    return CausalLMOutputWithPast(loss=loss, logits=None)
+                return {"loss": loss, "logits": None}
         logits = _lin(self.lm_head, hidden)                                          # :402-408
         loss = None
         if labels is not None and getattr(self.config, "fused_loss", False):

@@ -378,3 +378,37 @@ def test_finetune_stage_every_decoder_gradient(dev, monkeypatch, name, dt, tol_l
     assert n_dec >= 4 * 9 + 3, n_dec          # 4 decoder layers x (q, k, v, o, gate, up, down, 2 norms) + embeddings, final norm, lm_head
     assert n_all > n_dec + 50
     assert worst[1] < tol_grad, f"worst gradient {worst}"
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 4e-3)])
+@pytest.mark.parametrize("labels_on_cpu", [True, False])
+def test_scored_rows_loss_equals_the_full_one(dev, monkeypatch, dt, tol, labels_on_cpu):
+    """``config.fused_loss = "scored_rows"`` (round 5, opt-in): lm_head and the cross-entropy only over positions whose shifted
+    label is not IGNORE_INDEX.  Ignored rows add nothing to the loss and get zero gradient, so the loss and the gradient of every
+    trainable tensor must be the full computation's (only the GEMM's row count differs: fp32 2e-5, bf16 within a few ulps of the
+    activations); ``logits`` is not produced.  CPU labels (what the collator emits) avoid the device synchronisation."""
+    from cambrian_amd.train.data_layout import synthetic_batch
+    model, cfg, towers = _build(dev, dt, monkeypatch)
+    batch = synthetic_batch(2, seq_len=S, image_position=P0, image_token_len=SIDE * SIDE, aux_token_lens=[16, 64],
+                            image_res=[56, 64], image_sizes=[(336, 336), (336, 150)], vocab_lo=1, vocab_hi=300)
+    assert float((batch["labels"][:, 1:] == -100).float().mean()) > 0.1          # something IS ignored
+
+    def run(mode):
+        cfg.fused_loss = mode
+        model.zero_grad(set_to_none=True)
+        out = model(input_ids=batch["input_ids"].to(dev), attention_mask=batch["attention_mask"].to(dev),
+                    position_ids=batch["position_ids"].to(dev),
+                    labels=batch["labels"] if (labels_on_cpu and mode == "scored_rows") else batch["labels"].to(dev),
+                    images=[i.to(dev, dt) for i in batch["images"]],
+                    image_aux_attention_masks_list=[m.to(dev) for m in batch["image_aux_attention_masks_list"]],
+                    image_sizes=batch["image_sizes"])
+        out.loss.backward()
+        return out, {n: q.grad.detach().clone() for n, q in model.named_parameters() if q.requires_grad and q.grad is not None}
+
+    full, g_full = run(True)
+    part, g_part = run("scored_rows")
+    assert part.logits is None and full.logits is not None
+    assert abs(part.loss.item() - full.loss.item()) <= tol * max(1.0, abs(full.loss.item()))
+    assert set(g_full) == set(g_part) and len(g_full) > 50
+    worst = max((rel_err(g_part[n], g_full[n]), n) for n in g_full if g_full[n].abs().max() > 0)
+    assert worst[0] < 10 * tol, worst
