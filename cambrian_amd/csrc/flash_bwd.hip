@@ -16,6 +16,7 @@
 // Layout: all of q, k, v, o, do, dq, dk, dv are addressed as [B, S, H, 128] through (batch, token, head) element strides
 // (token-major storage, what ops.qkv_rope produces and the attention returns); lse / D are fp32 [B, H, S].
 #include "flash_common.h"
+#include "flash_layout.h"
 
 using namespace cmb_flash;
 
@@ -522,7 +523,12 @@ __global__ void __launch_bounds__(256, (CAUSAL && !PIPE) ? 2 : 1) flash_dq_kerne
 // ------------------------------------------------------------------------------------------------------------------
 // MASKED: a key-padding mask is given (causal only).  A separate instantiation: the unmasked kernels carry none of the mask's
 // registers or code (with a run-time pointer test instead they ran 3-8 % slower although every tile took the all-valid path).
-template <bool CAUSAL, bool MASKED, bool PIPE>
+// TR (round 5, knob bit 16): the transposed fragments (dO^T for dV, Q^T for dK) are read out of the ROW-major Q / dO images with
+// ds_read_b64_tr_b16 instead of out of transposed copies: the 64 ds_write_b32 and the ~100 16-bit shuffles per tile and thread
+// that built those copies are gone.  The row-major images are then un-padded and XOR-swizzled (flash_layout.h: 256-byte rows, slot ^
+// fl_swz(row)) — on the padded 272-byte rows a transposing read is 2-way bank-conflicted (the four rows of a [4][16] block start 16
+// bytes apart; measured: SQ_LDS_BANK_CONFLICT 54 % of the LDS-active cycles) — so that row-major AND transposing reads are conflict-free.
+template <bool CAUSAL, bool MASKED, bool PIPE, bool TR>
 __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);   // [64][LDR]
@@ -533,6 +539,16 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   float* sD = sLse + 64;                                    // [64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 5, j = lane & 31;
+  // TR: byte offsets of this lane's fragments inside a swizzled 64 x 128 image (flash_layout.h)
+  int kro_[KS], tro_[DT][2];
+  if (TR) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kro_[ks] = fl_row_frag_off(0, ks, lane);
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) tro_[d][r] = fl_tr_frag_off(0, 32 * d, r, lane);
+  }
   // Causal: key block kb meets (nkb - kb) * 2 query tiles per head, so a workgroup takes the PAIR (i, nkb-1-i) one
   // after the other — every workgroup does the same amount of work and the grid has no tail.
   const int nkb = p.S / 128;
@@ -592,13 +608,20 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
   } while (0)
 #define DKDV_PUT(sR_, sT_, a_, b_, rp_, dg_)                                          \
   do {                                                                                \
-    *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_)) * LDR + (dg_) * 8) = (a_);       \
-    *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_) + 1) * LDR + (dg_) * 8) = (b_);   \
-    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                \
-      bf16x2_t pr_;                                                                   \
-      pr_[0] = (a_)[e_];                                                              \
-      pr_[1] = (b_)[e_];                                                              \
-      *reinterpret_cast<bf16x2_t*>((sT_) + ((dg_) * 8 + e_) * LDT + 2 * (rp_)) = pr_; \
+    if (TR) {                                                                         \
+      *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_)) * 128 + (((dg_) ^ fl_swz(2 * (rp_))) << 3)) = (a_);         \
+      *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_) + 1) * 128 + (((dg_) ^ fl_swz(2 * (rp_) + 1)) << 3)) = (b_); \
+    } else {                                                                          \
+      *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_)) * LDR + (dg_) * 8) = (a_);     \
+      *reinterpret_cast<bf16x8_t*>((sR_) + (2 * (rp_) + 1) * LDR + (dg_) * 8) = (b_); \
+    }                                                                                 \
+    if (!TR) {                                                                        \
+      _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                              \
+        bf16x2_t pr_;                                                                 \
+        pr_[0] = (a_)[e_];                                                            \
+        pr_[1] = (b_)[e_];                                                            \
+        *reinterpret_cast<bf16x2_t*>((sT_) + ((dg_) * 8 + e_) * LDT + 2 * (rp_)) = pr_; \
+      }                                                                               \
     }                                                                                 \
   } while (0)
   DKDV_LOAD(hk * group, qt0);
@@ -618,14 +641,27 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
         if (!(last_q && hq + 1 == group)) DKDV_LOAD(nh, nq);
       }
       if (CAUSAL && qt * 64 + 63 < k0) continue;  // every query of the tile precedes this wave's keys
+      // 8-byte half r (0 / 1: rows + 8) of transposed fragment i = 8 qb16 + 2 d + w of half qs: w = 0 dO^T (dV), w = 1 Q^T (dK)
+      auto tr_half = [&](int qs, int i, int r) __attribute__((always_inline)) -> bf16x4_t {
+        if (TR) {
+          typedef short s16x4_v __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) s16x4_v* lds_s16x4_p;
+          const char* a_ = reinterpret_cast<const char*>((i & 1) ? sQ : sDO) + tro_[(i >> 1) & 3][r] + (qs * 32 + 16 * (i >> 3)) * FL_ROW_BYTES;
+          return __builtin_bit_cast(bf16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)a_));
+        }
+        const bf16_t* q_ = ((i & 1) ? sQT : sDOT) + (((i >> 1) & 3) * 32 + j) * LDT + qs * 32 + 16 * (i >> 3) + 4 * g;
+        return *reinterpret_cast<const bf16x4_t*>(q_ + 8 * r);
+      };
       // ---- one 64-query tile = two 32-query halves qs.  Pieces (all force-inlined; the same arithmetic in both orders):
       auto sdp = [&](int qs, f32x16_t& s, f32x16_t& dp) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(sQ + (qs * 32 + j) * LDR + ks * 16 + g * 8);
-          const bf16x8_t gf = *reinterpret_cast<const bf16x8_t*>(sDO + (qs * 32 + j) * LDR + ks * 16 + g * 8);
+          const bf16x8_t qf = TR ? *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const char*>(sQ) + kro_[ks] + qs * 32 * FL_ROW_BYTES)
+                                 : *reinterpret_cast<const bf16x8_t*>(sQ + (qs * 32 + j) * LDR + ks * 16 + g * 8);
+          const bf16x8_t gf = TR ? *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const char*>(sDO) + kro_[ks] + qs * 32 * FL_ROW_BYTES)
+                                 : *reinterpret_cast<const bf16x8_t*>(sDO + (qs * 32 + j) * LDR + ks * 16 + g * 8);
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);    // S[query][key]
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf, vf[ks], dp, 0, 0, 0);  // dP[query][key]
         }
@@ -668,12 +704,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
           const bf16x8_t dsf = cvt8(s[o8], s[o8 + 1], s[o8 + 2], s[o8 + 3], s[o8 + 4], s[o8 + 5], s[o8 + 6], s[o8 + 7]);
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
-            const bf16_t* grow = sDOT + (d * 32 + j) * LDT + qs * 32 + 16 * qb16 + 4 * g;
-            const bf16_t* qrow_t = sQT + (d * 32 + j) * LDT + qs * 32 + 16 * qb16 + 4 * g;
-            const bf16x4_t g_lo = *reinterpret_cast<const bf16x4_t*>(grow);
-            const bf16x4_t g_hi = *reinterpret_cast<const bf16x4_t*>(grow + 8);
-            const bf16x4_t q_lo = *reinterpret_cast<const bf16x4_t*>(qrow_t);
-            const bf16x4_t q_hi = *reinterpret_cast<const bf16x4_t*>(qrow_t + 8);
+            const bf16x4_t g_lo = tr_half(qs, 8 * qb16 + 2 * d, 0), g_hi = tr_half(qs, 8 * qb16 + 2 * d, 1);
+            const bf16x4_t q_lo = tr_half(qs, 8 * qb16 + 2 * d + 1, 0), q_hi = tr_half(qs, 8 * qb16 + 2 * d + 1, 1);
             bf16x8_t gt, qtf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { gt[e] = g_lo[e]; gt[4 + e] = g_hi[e]; qtf[e] = q_lo[e]; qtf[4 + e] = q_hi[e]; }
@@ -700,11 +732,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
         f32x4_t lq[4], dq4[4];
         // product i = 2 ks + w of a score phase: w = 0 S (Q rows x K fragment), w = 1 dP (dO rows x V fragment)
         auto row_frag = [&](int qs, int i) __attribute__((always_inline)) -> bf16x8_t {
+          if (TR) return *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const char*>((i & 1) ? sDO : sQ) + kro_[i >> 1] + qs * 32 * FL_ROW_BYTES);
           return *reinterpret_cast<const bf16x8_t*>(((i & 1) ? sDO : sQ) + (qs * 32 + j) * LDR + (i >> 1) * 16 + g * 8);
-        };
-        // product i = 8 qb16 + 2 d + w of a gradient phase: w = 0 dV (dO^T rows of d tile d), w = 1 dK (Q^T rows)
-        auto tr_ptr = [&](int qs, int i) __attribute__((always_inline)) -> const bf16_t* {
-          return ((i & 1) ? sQT : sDOT) + (((i >> 1) & 3) * 32 + j) * LDT + qs * 32 + 16 * (i >> 3) + 4 * g;
         };
         auto load_ld = [&](int qs) __attribute__((always_inline)) {
 #pragma unroll
@@ -754,9 +783,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
         bf16x4_t tlo[4], thi[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const bf16_t* q_ = tr_ptr(0, i);
-          tlo[i] = *reinterpret_cast<const bf16x4_t*>(q_);
-          thi[i] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+          tlo[i] = tr_half(0, i, 0);
+          thi[i] = tr_half(0, i, 1);
         }
         FLASH_FENCE();
         // ---- C: dV0, dK0  +  the second half's probabilities
@@ -769,9 +797,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
           if (i & 1) adk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, dsf[i >> 3], adk[d], 0, 0, 0);
           else adv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[i >> 3], adv[d], 0, 0, 0);
           {
-            const bf16_t* q_ = tr_ptr(i + 4 < 16 ? 0 : 1, (i + 4) & 15);   // runs on into phase D's first four
-            tlo[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_);
-            thi[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+            tlo[i & 3] = tr_half(i + 4 < 16 ? 0 : 1, (i + 4) & 15, 0);   // runs on into phase D's first four
+            thi[i & 3] = tr_half(i + 4 < 16 ? 0 : 1, (i + 4) & 15, 1);
           }
           elem(i, s1, dp1, pr1);
           FLASH_FENCE();
@@ -793,9 +820,8 @@ __global__ void __launch_bounds__(256) flash_dkdv_kernel(const FlashParams p) {
           if (i & 1) adk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, dsf[i >> 3], adk[d], 0, 0, 0);
           else adv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf, pf[i >> 3], adv[d], 0, 0, 0);
           if (i + 4 < 16) {
-            const bf16_t* q_ = tr_ptr(1, i + 4);
-            tlo[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_);
-            thi[i & 3] = *reinterpret_cast<const bf16x4_t*>(q_ + 8);
+            tlo[i & 3] = tr_half(1, i + 4, 0);
+            thi[i & 3] = tr_half(1, i + 4, 1);
           }
           FLASH_FENCE();
         }
@@ -859,8 +885,10 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   if (!attr_done) {
     bool ok = true;
 #define DKDV_ATTR(C_, M_, P_)                                                                                   \
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<C_, M_, P_>),                  \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess
+  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<C_, M_, P_, false>),           \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess &&              \
+       hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<C_, M_, P_, true>),                  \
+                           hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess
     DKDV_ATTR(true, true, false); DKDV_ATTR(true, false, false); DKDV_ATTR(false, false, false);
     DKDV_ATTR(true, true, true); DKDV_ATTR(true, false, true); DKDV_ATTR(false, false, true);
 #undef DKDV_ATTR
@@ -870,7 +898,7 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   // knob bits: 2 = dQ on LDS-DMA tiles (flash2.hip), 8 = dK/dV on LDS-DMA tiles (flash2.hip; needs bit 2: that dQ kernel
   // writes the second half of dvec), 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 0 = round 4
   const int knob = cmb_knob(CMB_KNOB_FLASH);
-  const bool pipe_q = (knob & 2) != 0, pipe_k = (knob & 4) != 0, k2 = (knob & 8) != 0 && pipe_q;
+  const bool pipe_q = (knob & 2) != 0, pipe_k = (knob & 4) != 0, k2 = (knob & 8) != 0 && pipe_q, tr_k = (knob & 16) != 0;
 #define FLASH_BWD_LAUNCH(C_, M_)                                                                      \
   do {                                                                                                \
     if (pipe_q) {                                                                                     \
@@ -880,8 +908,10 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
     if (k2) {                                                                                         \
       const int rc_ = launch_flash_dkdv2(p, C_, s);                                                   \
       if (rc_ != CMB_OK) return rc_;                                                                  \
-    } else if (pipe_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, true>), gk, dim3(256), smem, s, p); \
-    else hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, false>), gk, dim3(256), smem, s, p);           \
+    } else if (pipe_k && tr_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, true, true>), gk, dim3(256), smem, s, p); \
+    else if (pipe_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, true, false>), gk, dim3(256), smem, s, p); \
+    else if (tr_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, false, true>), gk, dim3(256), smem, s, p); \
+    else hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, false, false>), gk, dim3(256), smem, s, p);    \
   } while (0)
   if (causal && p.key_valid) FLASH_BWD_LAUNCH(true, true);
   else if (causal) FLASH_BWD_LAUNCH(true, false);

@@ -83,12 +83,13 @@ int cmb_abi_version(void);
  *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
  *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 7 (one wave per SIMD) or 4 (two)
  *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask: 1 = forward, 2 = dQ, 8 = dK/dV on LDS-DMA operand tiles with transposing
- *                       reads (flash2.hip; 8 needs 2); 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 0 = the
- *                       round-4 kernels.  Default 7 (the LDS-DMA dK/dV kernel measured slower than 4: profiles/r05_lab.md).  dQ / dK / dV are
- *                       bit-identical across variants, the forward to fp32 rounding */
+ *                       reads (flash2.hip; 8 needs 2); 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 16 = that
+ *                       kernel reading its Q^T / dO^T fragments with transposing reads from swizzled row-major images (no transposed
+ *                       copies); 0 = the round-4 kernels.  Default 23 (the LDS-DMA dK/dV kernel measured slower than 4 | 16:
+ *                       profiles/r05_lab.md).  dQ / dK / dV are bit-identical across variants, the forward to fp32 rounding */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
                    CMB_KNOB_FLASH = 5, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 7, 0, 0
+#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 23, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 

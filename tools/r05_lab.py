@@ -73,8 +73,8 @@ def flash_case(B, S=2048, H=32, HKV=8, masked=False, causal=True):
         o.backward(do)
         return o.detach(), qq.grad, kk.grad, vv.grad
 
-    a, b_ = run(0), run(15)
-    c_ = run(14)   # round-4 forward + the round-5 backward kernels: dq / dk / dv must be bit-identical to knob 0
+    a, b_ = run(0), run(23)
+    c_ = run(22)   # round-4 forward + the round-5 backward kernels: dq / dk / dv must be bit-identical to knob 0
     names = ["out", "dq", "dk", "dv"]
     eq = {n: bool(torch.equal(x, y)) for n, x, y in zip(names, a, b_)}
     err = {n: float((x.float() - y.float()).abs().max() / x.float().abs().max()) for n, x, y in zip(names, a, b_)}
@@ -90,7 +90,7 @@ def flash_case(B, S=2048, H=32, HKV=8, masked=False, causal=True):
         return f
 
     outs = {}
-    for knob in (0, 2, 6, 10):
+    for knob in (0, 6, 22):
         L.knob_set(L.KNOB_FLASH, knob)
         outs[knob] = ops.CausalAttnFn.apply(qq, kk, vv, None, kv_len, kvalid)
 
@@ -100,9 +100,9 @@ def flash_case(B, S=2048, H=32, HKV=8, masked=False, causal=True):
             torch.autograd.grad(outs[knob], (qq, kk, vv), do, retain_graph=True)
         return f
 
-    t = time_variants({"fwd_old": fwd(0), "fwd_new": fwd(1), "bwd_old": bwd(0), "bwd_dq2": bwd(2), "bwd_dq2_dkdvpipe": bwd(6),
-                       "bwd_new": bwd(10)}, iters=5, rounds=3)
-    L.knob_set(L.KNOB_FLASH, 15)
+    t = time_variants({"fwd_old": fwd(0), "fwd_new": fwd(1), "bwd_old": bwd(0), "bwd_dq2_dkdvpipe": bwd(6),
+                       "bwd_new": bwd(22)}, iters=5, rounds=3)
+    L.knob_set(L.KNOB_FLASH, 7)
     fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
     emit({"case": "flash", "B": B, "S": S, "H": H, "HKV": HKV, "causal": causal, "masked": masked, "bit_equal_all_new": eq, "bit_equal_bwd_only_new": eq_bwd, "max_rel": err,
           "us": t, "fwd_TFLOPs": {k_: round(fl / t[k_] / 1e6, 1) for k_ in ("fwd_old", "fwd_new")},
