@@ -3,6 +3,7 @@
 #   tools/gpu_r05.sh bench            the driver's command, line -> gpurun_out/r05/bench_<tag>.json
 #   tools/gpu_r05.sh prof [steps]     rocprofv3 --kernel-trace --stats of the driver's command -> kernel_stats.md + timeline.json
 #   tools/gpu_r05.sh tests [expr]     pytest -m gpu (optionally -k expr) + smoke
+#   tools/gpu_r05.sh shapes           bench.py --gemm-report: per-shape GEMM table of a step
 #   tools/gpu_r05.sh lab <args...>    python tools/r05_lab.py <args...>
 #   tools/gpu_r05.sh py <file> ...    python <file> ...
 # several verbs in one call: separate with '--'  (e.g. `tools/gpu_r05.sh bench -- prof`)
@@ -48,6 +49,15 @@ try:
 except Exception as e: print("parse failed", e); print(open("$O/mode_$n.err").read()[-1500:])
 P
       done
+      ;;
+    shapes)  # per-shape table of every own GEMM launch of a step (an event pair per launch) -> gemm_shapes_<tag>.json
+      timeout 500 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ab --no-masked-case --gemm-report $O/gemm_shapes_$TAG.json > $O/gemm_report_run_$TAG.json 2> $O/gemm_report_run_$TAG.err
+      echo "gemm report rc=$?"; python - <<P
+import json
+rows=sorted(json.load(open("$O/gemm_shapes_$TAG.json")), key=lambda r: -r["ms_per_step"])
+print(len(rows), "shapes", round(sum(r["ms_per_step"] for r in rows),1), "ms per step")
+for r in rows[:14]: print(r["M"], r["N"], r["K"], "act", r["act"], "x", r["launches_per_step"], round(r["ms_per_step"],2), "ms", round(r["TFLOPs"]), "TF", round(r["TFLOPs"]/2500,3))
+P
       ;;
     lab) timeout 300 python tools/r05_lab.py "$@" 2>&1 | tail -60 ;;
     pmcflash)   # SQ counter passes (separate --pmc runs, --kernel-trace only) of the flash kernels: pmcflash <knob> <fwd|bwd> <kernel substring...>
