@@ -94,6 +94,11 @@ __global__ void __launch_bounds__(256, 2) flash_fwd2_kernel(const FlashParams p,
     bf16x8_t qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + g * 8);
+    // The fragments are awaited HERE.  Left to the compiler, their first uses inside the tile loop carry `s_waitcnt vmcnt(7 .. 0)`
+    // (the eight loads above, counted without the LDS-DMA instructions it cannot see) on EVERY tile — and a vmcnt(0) in the
+    // middle of a tile waits for the next tile's fills, issued a moment earlier: the prefetch ran serialised with the S products.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     const char* kbase = uniform_ptr(reinterpret_cast<const char*>(p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh));
     const char* vbase = uniform_ptr(reinterpret_cast<const char*>(p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh));
     const int64_t tile_bytes = (int64_t)64 * p.kv_ss * 2;   // global bytes from one tile's first row to the next's
@@ -333,8 +338,12 @@ __global__ void __launch_bounds__(256, 2) flash_dq2_kernel(const FlashParams p) 
       dq_d += __shfl_xor(dq_d, 32, 64);
       if (g == 0) p.dvec[st] = dq_d;
     }
-    const float lse2 = p.lse[st] * LOG2E;
+    float lse2 = p.lse[st] * LOG2E;
     if (g == 0) p.dvec[(int64_t)p.B * p.H * p.S + st] = lse2;   // second half of dvec: what flash_dkdv2_kernel exponentiates against
+    // every prologue load is awaited here, not by stale vmcnt waits inside the tile loop (see flash_fwd2_kernel)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
+    asm volatile("" : "+v"(lse2), "+v"(dq_d));
     const char* kbase = uniform_ptr(reinterpret_cast<const char*>(p.k + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh));
     const char* vbase = uniform_ptr(reinterpret_cast<const char*>(p.v + (int64_t)b * p.kv_sb + (int64_t)hk * p.kv_sh));
     const int64_t tile_bytes = (int64_t)64 * p.kv_ss * 2;
@@ -515,6 +524,8 @@ __global__ void __launch_bounds__(256) flash_dkdv2_kernel(const FlashParams p) {
       kf[ks] = *reinterpret_cast<const bf16x8_t*>(krow + ks * 16 + g * 8);
       vf[ks] = *reinterpret_cast<const bf16x8_t*>(vrow + ks * 16 + g * 8);
     }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // awaited here (see flash_fwd2_kernel)
     // key-padding mask: this lane's key is padded -> only its own query (the open diagonal) contributes
     const bool kvalid = !MASKED || p.key_valid[(int64_t)b * p.S + ki] != 0;
     const bool wave_padded = MASKED && __builtin_amdgcn_ballot_w64(!kvalid) != 0;
