@@ -619,6 +619,9 @@ def compact_line(full: dict) -> dict:
             out["all_own_gemm_frac"] = ag.get("frac")
             out["all_own_gemm_ms_per_step"] = ag.get("ms_per_step")
             out["all_own_gemm_tflop_per_step"] = ag.get("tflop_per_step")
+            for fam, v in (ag.get("families") or {}).items():   # weight-gradient (TN) and 128-tile launches beside the 256-tile kernels
+                out[f"own_{fam}_ms_per_step"] = round(v["ms_per_step"], 2)
+                out[f"own_{fam}_frac"] = round(v["frac"], 4)
         ab = (rf.get("ab") or {}).get("variants")
         if ab:
             out["ab_shape_MNK"] = "x".join(str(v) for v in rf["ab"]["shape_MNK"])
@@ -1026,6 +1029,12 @@ def main():
                     "frac": fall / (msall * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if msall > 0 else 0.0,
                     "launches_per_step": nall / gemm_pass_steps, "ms_per_step": msall / gemm_pass_steps,
                     "tflop_per_step": fall / gemm_pass_steps / 1e12,
+                    "families": {name: {"ms_per_step": ms_ / gemm_pass_steps, "launches_per_step": n_ / gemm_pass_steps,
+                                        "frac": (fl_ / (ms_ * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS) if ms_ > 0 else 0.0}
+                                 for name, (fl_, ms_, n_) in (
+                                     (nm, agg(prof_all, lambda x, kid=kid: x[3] == torch.bfloat16 and x[7] == kid))
+                                     for nm, kid in (("gemm_nt_p5", 2590), ("gemm_nt_256_8wave", 256), ("gemm_nt_128", 128),
+                                                     ("gemm_tn", 7128)))},
                     "from": f"{gemm_pass_steps} extra profiled steps after the timed region (an event pair around every own bf16 "
                             "GEMM launch: 128- and 256-tile kernels, split-K wgrad GEMMs with their reduce kernels)"}
                 if "region" in line["roofline"]:
@@ -1042,13 +1051,15 @@ def main():
         if prof_all and args.gemm_report:
             shapes = {}
             for x in prof_all:
-                key = (x[6], x[4], x[5], x[7])
+                key = (x[6], x[4], x[5], x[7], x[8] if len(x) > 8 else 1)
                 s_ = shapes.setdefault(key, [0, 0.0, 0.0])
                 s_[0] += 1
                 s_[1] += x[0].elapsed_time(x[1])
                 s_[2] += x[2]
+            # kernel: 2590 gemm_nt_p5, 256 gemm_nt_256 (8 waves), 128 gemm_nt<128,128> (batch > 1: the per-head launches of the
+            # absorbed SVA path), 7128 cmb_gemm_tn (weight gradients; K = contraction rows, the span includes its split-K reduce)
             rows = [{"M": k[0][0], "N": k[0][1], "K": k[0][2], "act": k[0][3], "f32_out": k[0][4], "split_k": k[1], "tile": k[2],
-                     "kernel": k[3], "launches_per_step": v[0] / gemm_pass_steps, "ms_per_step": v[1] / gemm_pass_steps,
+                     "kernel": k[3], "batch": k[4], "launches_per_step": v[0] / gemm_pass_steps, "ms_per_step": v[1] / gemm_pass_steps,
                      "TFLOPs": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0} for k, v in shapes.items()]
             rows.sort(key=lambda r: -r["ms_per_step"])
             with open(args.gemm_report, "w") as f:

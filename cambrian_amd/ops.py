@@ -242,6 +242,7 @@ def fp8_linear_eligible(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 # bench.py sets this to a list to collect (start_event, end_event, flops, dtype, split_k, tile, shape, kernel id) per GEMM launch
 GEMM_PROFILE = None
+KERNEL_ID_TN = 7128   # the `kernel` field of cmb_gemm_tn launches in GEMM_PROFILE rows (cmb_gemm_last_kernel ids: 128, 256, 2590)
 GEMM_PROFILE_TILE = 0  # 0 = time every GEMM launch; 128 / 256 = only launches of that tile configuration
 # {(M, N, K, act, has_pre_out): launches} of the bf16 launches that left the kernel choice to the library, while set to a dict
 GEMM_CENSUS = None
@@ -429,8 +430,14 @@ def k_gemm_tn(at: torch.Tensor, bt: torch.Tensor, *, out: Optional[torch.Tensor]
     else:
         d.workspace, d.workspace_bytes = None, 0
     d.batch, d.a_batch_stride, d.b_batch_stride, d.c_batch_stride = batch, a_bs, b_bs, c_bs
+    prof = GEMM_PROFILE if not GEMM_PROFILE_TILE else None   # (the timed region times the dominant kernel only)
+    if prof is not None:
+        e0 = _event()
     rc = L.load().cmb_gemm_tn(C.byref(d), L.stream_ptr(at.device))
     L.check(rc, f"cmb_gemm_tn(M={M}, N={N}, K={K}, batch={batch})")
+    if prof is not None:   # the span covers the split-K reduce the library launches behind the kernel
+        prof.append((e0, _event(), 2.0 * max(batch, 1) * M * N * K, at.dtype, split_k, 128,
+                     (M, N, K, L.ACT_NONE, out.dtype == torch.float32), KERNEL_ID_TN, max(batch, 1)))
     return out
 
 
@@ -967,8 +974,14 @@ def k_gemm_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch
     d.act, d.alpha, d.beta, d.split_k, d.tile_hint = L.ACT_NONE, 1.0, 0.0, 1, 0
     d.workspace, d.workspace_bytes = None, 0
     d.batch, d.a_batch_stride, d.b_batch_stride, d.c_batch_stride = batch, a_bs, b_bs, c_bs
+    prof = GEMM_PROFILE if not GEMM_PROFILE_TILE else None
+    if prof is not None:
+        e0 = _event()
     rc = L.load().cmb_gemm(C.byref(d), L.stream_ptr(a.device))
     L.check(rc, f"cmb_gemm(batch={batch}, M={M}, N={N}, K={K})")
+    if prof is not None:
+        prof.append((e0, _event(), 2.0 * batch * M * N * K, a.dtype, 1, 128, (M, N, K, L.ACT_NONE, out.dtype == torch.float32),
+                     L.load().cmb_gemm_last_kernel(), batch))
     return out
 
 

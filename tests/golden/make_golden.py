@@ -19,7 +19,8 @@ import types
 import torch
 
 REF = "/root/reference"
-OUT = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("CAMBRIAN_GOLDEN_OUT") or HERE   # (tests/test_golden_regen.py writes elsewhere)
 
 
 def load_ref_vision_sampler():
@@ -99,7 +100,7 @@ def golden_sva_k1024():
     query grid 4 x 4, one image) so that the fixture replays straight through the HIP module (one hop: reference ->
     HIP), for q_dim 1024 (connector) and 4096 (in-LLM).  Weights come from tests/golden_recipes.fill_state (not stored:
     15.8 M / 22 M parameters); parameter gradients are stored as summaries (sum, norm, 3 seeded projections)."""
-    sys.path.insert(0, os.path.dirname(OUT))
+    sys.path.insert(0, os.path.dirname(HERE))
     from golden_recipes import fill_state, grad_summary, sva_k1024_inputs
     vs = load_ref_vision_sampler()
     fx = {}
@@ -400,7 +401,7 @@ def golden_llama():
     print("llama_small.pt written")
 
 
-def golden_arch_dynamic():
+def golden_arch_dynamic(query_nums=None):
     """The real prepare_inputs_labels_for_multimodal with IS_XLA_AVAILABLE = False: the eval / generate branch
     (cambrian_arch.py:289-330 rearrange_inference + unpad, :422-451 per-sample unpad + newline, :492-609 variable-length
     merge) with fake towers, non-square images and a padded batch; plus the dynamic in-LLM hook, cambrian_llama.py lines

@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round 5: ONE parametrised gpurun command file (no per-call scratch scripts).
-#   tools/gpu_r05.sh bench            the driver's command, line -> gpurun_out/r05/bench_<tag>.json
-#   tools/gpu_r05.sh prof [steps]     rocprofv3 --kernel-trace --stats of the driver's command -> kernel_stats.md + timeline.json
-#   tools/gpu_r05.sh tests [expr]     pytest -m gpu (optionally -k expr) + smoke
-#   tools/gpu_r05.sh shapes           bench.py --gemm-report: per-shape GEMM table of a step
-#   tools/gpu_r05.sh lab <args...>    python tools/r05_lab.py <args...>
-#   tools/gpu_r05.sh py <file> ...    python <file> ...
-# several verbs in one call: separate with '--'  (e.g. `tools/gpu_r05.sh bench -- prof`)
+# ONE parametrised gpurun command file (rounds 5+; no per-call scratch scripts).  ROUND=r06 (default) names the output folder.
+#   tools/gpu_run.sh bench            the driver's command, line -> gpurun_out/r05/bench_<tag>.json
+#   tools/gpu_run.sh prof [steps]     rocprofv3 --kernel-trace --stats of the driver's command -> kernel_stats.md + timeline.json
+#   tools/gpu_run.sh tests [expr]     pytest -m gpu (optionally -k expr) + smoke
+#   tools/gpu_run.sh shapes           bench.py --gemm-report: per-shape GEMM table of a step
+#   tools/gpu_run.sh lab <args...>    python tools/r05_lab.py <args...>
+#   tools/gpu_run.sh py <file> ...    python <file> ...
+# several verbs in one call: separate with '--'  (e.g. `tools/gpu_run.sh bench -- prof`)
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/${ROUND:-r06}; mkdir -p $O
 TAG=${TAG:-$(date +%H%M%S)}
 run_verb() {
   local verb=$1; shift

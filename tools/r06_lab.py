@@ -1,0 +1,144 @@
+"""Round-6 kernel lab (GPU): variants timed round-robin in one process, one JSON line per (case, variant).
+
+    python tools/r06_lab.py gemmtiles          the region's laggard GEMM shapes on every tile configuration (2590 = 4-wave
+                                                persistent, 2560 = 8-wave, 128 = 128 x 128 two workgroups per CU), real epilogues
+    python tools/r06_lab.py attn               ViT attention: kernel variants (CMB_KNOB_VIT_ATTN) at the three towers' shapes
+    python tools/r06_lab.py tn                 weight-gradient shapes: cmb_gemm_tn split-K sweep, batched form
+    python tools/r06_lab.py lnmulti|casts|...  see the verbs below
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from cambrian_amd import lib as L  # noqa: E402
+from cambrian_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("verbs", nargs="+")
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--images", type=int, default=24)
+ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06", "lab.jsonl"))
+ap.add_argument("--tag", default="")
+args = ap.parse_args()
+B = args.images
+dev = torch.device("cuda", 0)
+bf, f32 = torch.bfloat16, torch.float32
+os.makedirs(os.path.dirname(args.out), exist_ok=True)
+fout = open(args.out, "a")
+
+
+def rn(*shape, dtype=bf, scale=1.0):
+    return (torch.randn(*shape, device=dev, dtype=torch.float32) * scale).to(dtype)
+
+
+def emit(**kw):
+    kw["tag"] = args.tag
+    line = json.dumps(kw)
+    print(line, flush=True)
+    fout.write(line + "\n")
+    fout.flush()
+
+
+def time_variants(fns: dict, iters=None, warm=2):
+    """{name: fn} -> {name: median us}; variants interleaved round-robin, an event pair per launch."""
+    iters = iters or args.iters
+    for _ in range(warm):
+        for f in fns.values():
+            f()
+    torch.cuda.synchronize()
+    evs = {k: [] for k in fns}
+    for _ in range(iters):
+        for k, f in fns.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            f()
+            e1.record()
+            evs[k].append((e0, e1))
+    torch.cuda.synchronize()
+    out = {}
+    for k, lst in evs.items():
+        t = sorted(a.elapsed_time(b) * 1e3 for a, b in lst)
+        out[k] = t[len(t) // 2]
+    return out
+
+
+verbs = set(args.verbs)
+
+if "gemmtiles" in verbs:
+    G = L.ACT_CODES["gelu_erf"]
+    cases = [  # name, M, N, K, act, bias, colscale, residual
+        ("ConvNeXt s1 fc1", B * 65536, 1536, 384, G, True, False, False),
+        ("ConvNeXt s1 fc2", B * 65536, 384, 1536, 0, True, True, True),
+        ("ConvNeXt s2 fc1", B * 16384, 3072, 768, G, True, False, False),
+        ("ConvNeXt s2 fc2", B * 16384, 768, 3072, 0, True, True, True),
+        ("DINOv2 proj", B * 730, 1536, 1536, 0, True, True, True),
+        ("DINOv2 fc2", B * 730, 1536, 4096, 0, True, True, True),
+        ("DINOv2 qkv", B * 730, 4608, 1536, 0, True, False, False),
+        ("SigLIP proj", B * 729, 1152, 1536, 0, True, False, True),
+        ("SigLIP fc2", B * 729, 1152, 4352, 0, True, False, True),
+        ("SVA q-side 1024", B * 576, 1024, 1024, 0, False, False, False),
+        ("SVA q-side 2048", B * 576, 2048, 1024, 0, False, False, False),
+    ]
+    for name, M, N, K, act, hb, hcs, hr in cases:
+        a, w = rn(M, K), rn(N, K, scale=K ** -0.5)
+        bias = rn(N, dtype=f32) if hb else None
+        cs = rn(N, dtype=f32) if hcs else None
+        res = rn(M, N) if hr else None
+        out = torch.empty(M, N, device=dev, dtype=bf)
+        fns = {}
+        for tile in (2590, 2560, 128):
+            fns[str(tile)] = (lambda tile=tile: ops.k_gemm(a, w, bias=bias, act=act, colscale=cs, residual=res, out=out, tile=tile))
+        ref = None
+        same = {}
+        for k, f in fns.items():
+            f()
+            if ref is None:
+                ref = out.clone()
+            same[k] = bool(torch.equal(out, ref))
+        us = time_variants(fns)
+        emit(case="gemmtiles", shape=f"{name} {M}x{N}x{K} act{act} b{int(hb)}cs{int(hcs)}r{int(hr)}",
+             us={k: round(v, 1) for k, v in us.items()}, tflops={k: round(2.0 * M * N * K / v / 1e6) for k, v in us.items()},
+             bit_equal=same)
+        del a, w, out, res, ref
+
+if "attn" in verbs:
+    from cambrian_amd.model.multimodal_encoder import vit_ops as V
+    for name, N, heads, hd in (("CLIP", 577, 16, 64), ("DINOv2", 730, 24, 64), ("SigLIP", 729, 16, 72)):
+        hdp = 96 if hd == 72 else hd
+        qkv = rn(B * N, 3 * heads * hdp, scale=1.0)
+        fns, ref, same = {}, None, {}
+        for var in (0, 1, 2):
+            try:
+                L.knob_set(L.KNOB_VIT_ATTN, var)
+            except Exception:
+                continue
+            fns[str(var)] = (lambda var=var: (L.knob_set(L.KNOB_VIT_ATTN, var), V.k_vit_attn(qkv, B, N, heads, hdp, hd ** -0.5))[1])
+            y = fns[str(var)]()
+            if ref is None:
+                ref = y
+            same[str(var)] = float((y.float() - ref.float()).abs().max())
+        us = time_variants(fns, iters=20)
+        flops = 4.0 * B * heads * N * N * hd
+        emit(case="vit_attn", shape=f"{name} N={N} heads={heads} hd={hd}", us={k: round(v, 1) for k, v in us.items()},
+             useful_tflops={k: round(flops / v / 1e6) for k, v in us.items()}, max_abs_diff_vs_v0=same)
+        L.knob_set(L.KNOB_VIT_ATTN, 1)
+        del qkv
+
+if "tn" in verbs:
+    R = B * 576
+    for name, n_out, k_in in (("1024x1024", 1024, 1024), ("2048x1024", 2048, 1024), ("1024x2048", 1024, 2048),
+                              ("4096x1024", 4096, 1024), ("1024x4096", 1024, 4096), ("1024x5120", 1024, 5120)):
+        g, x = rn(R, n_out), rn(R, k_in)
+        fns = {}
+        for sp in (1, 2, 4, 8, 16):
+            fns[f"tn_split{sp}"] = (lambda sp=sp: ops.k_gemm_tn(g, x, split_k=sp))
+        fns["auto"] = lambda: ops.k_gemm_tn(g, x, split_k=ops._tn_splits(n_out, k_in, R))
+        us = time_variants(fns)
+        emit(case="tn", shape=f"dW {name} from {R} rows", us={k: round(v, 1) for k, v in us.items()},
+             tflops={k: round(2.0 * R * n_out * k_in / v / 1e6) for k, v in us.items()}, auto_split=ops._tn_splits(n_out, k_in, R))
+        del g, x
