@@ -46,6 +46,60 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight_prep: for a TABLE of 2-D weights (fp32 masters or bf16), one launch writes each one's bf16 copy [rows, cols] and its
+// transposed bf16 copy [cols, rows_pad] (zero columns rows .. rows_pad - 1) — the per-use cmb_cast + cmb_transpose pairs of the
+// trainable linears (round 5: 171 + 166 launches of 5-12 us per step) as ONE pass over the masters (round 6).  A workgroup
+// owns one 64 x 64 tile; the job of a tile is found by bisection over the jobs' first-tile prefix.
+// ---------------------------------------------------------------------------------------------
+template <bool ONE>
+__global__ void __launch_bounds__(256) weight_prep_kernel(const cmb_prep_job one, const cmb_prep_job* __restrict__ jobs, int n_jobs) {
+  constexpr int TS = 64, LD = TS + 2;
+  __shared__ bf16_t tile[TS * LD];
+  const int b = (int)blockIdx.x;
+  const cmb_prep_job* jp = &one;
+  if (!ONE) {
+    int lo = 0, hi = n_jobs - 1;   // last job with tile0 <= b
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].tile0 <= b) lo = mid;
+      else hi = mid - 1;
+    }
+    jp = jobs + lo;
+  }
+  const cmb_prep_job j = *jp;
+  const int tiles_c = (j.cols + TS - 1) / TS;
+  const int tl = b - j.tile0;
+  const int64_t r0 = (int64_t)(tl / tiles_c) * TS, c0 = (int64_t)(tl % tiles_c) * TS;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = t / 8 + 32 * i, cv = t % 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t gr = r0 + row, gc = c0 + cv * 8;
+    if (gr < j.rows && gc < j.cols) {
+      if (j.src_dtype == CMB_F32) Vec8<float>::load(reinterpret_cast<const float*>(j.src) + gr * j.ld_src + gc, v);
+      else Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(j.src) + gr * j.ld_src + gc, v);
+      if (j.dst) Vec8<bf16_t>::store(reinterpret_cast<bf16_t*>(j.dst) + gr * j.cols + gc, v);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[row * LD + cv * 8 + e] = (bf16_t)v[e];
+  }
+  if (!j.dst_t) return;   // (uniform per workgroup)
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = t / 8 + 32 * i, rv = t % 8;
+    const int64_t gc = c0 + c, gr = r0 + rv * 8;
+    if (gc < j.cols && gr < j.rows_pad) {
+      bf16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = tile[(rv * 8 + e) * LD + c];
+      *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16_t*>(j.dst_t) + gc * j.rows_pad + gr) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // colsum: out[c] += sum_r in[r, c]  (fp32 atomics, one per column per block)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -388,6 +442,33 @@ extern "C" int cmb_transpose(int dtype, const void* in, int64_t R, int64_t C, in
   return CMB_OK;
 }
 
+static int prep_job_ok(const cmb_prep_job& j) {
+  return j.src && (j.dst || j.dst_t) && (j.src_dtype == CMB_F32 || j.src_dtype == CMB_BF16) && j.rows > 0 && j.cols > 0 &&
+         !(j.cols & 7) && !(j.rows_pad & 7) && j.rows_pad >= j.rows && !(j.ld_src & 7) && j.ld_src >= j.cols;
+}
+
+extern "C" int64_t cmb_weight_prep_tiles(int64_t rows_pad, int64_t cols) { return ((rows_pad + 63) / 64) * ((cols + 63) / 64); }
+
+extern "C" int cmb_weight_prep_one(const cmb_prep_job* job, void* stream) {
+  if (!job || !prep_job_ok(*job)) return CMB_ERR_BAD_ARG;
+  cmb_prep_job j = *job;
+  j.tile0 = 0;
+  const int64_t tiles = cmb_weight_prep_tiles(j.rows_pad, j.cols);
+  if (tiles > 0x7fffffff) return CMB_ERR_BAD_ARG;
+  hipLaunchKernelGGL(weight_prep_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, j, nullptr, 1);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_weight_prep(const cmb_prep_job* jobs_device, int32_t n_jobs, int64_t total_tiles, void* stream) {
+  if (!jobs_device || n_jobs <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffff) return CMB_ERR_BAD_ARG;
+  cmb_prep_job none = {};
+  hipLaunchKernelGGL(weight_prep_kernel<false>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, none,
+                     jobs_device, n_jobs);
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
 extern "C" int cmb_colsum(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in, float* out, void* stream) {
   if (!in || !out || R < 0 || C <= 0 || (C & 7) || (ld_in & 7)) return CMB_ERR_BAD_ARG;
   if (R == 0) return CMB_OK;
@@ -564,7 +645,7 @@ extern "C" int cmb_knob_set(int32_t knob, int32_t value) {
   switch (knob) {
     case CMB_KNOB_LN_FWD: ok = value >= 0 && value <= 65536; break;           // 0 / 1 / workgroup cap
     case CMB_KNOB_DWCONV: ok = value >= 0 && value <= 4096; break;            // 0 / 1 / rows per chunk
-    case CMB_KNOB_VIT_ATTN: ok = value == 0 || value == 1; break;
+    case CMB_KNOB_VIT_ATTN: ok = value >= 0 && value <= 3; break;              // 2 = LDS-DMA tiles + transposing reads (round 6)
     case CMB_KNOB_SVA_ABS: ok = value == 0 || value == 1; break;
     case CMB_KNOB_LN_MULTI_CHUNK: ok = value == 4 || value == 7; break;
     case CMB_KNOB_FLASH: ok = value >= 0 && value <= 31; break;   // bit mask: 1 forward, 2 dQ, 4 dK/dV body, 8 dK/dV tiles, 16 dK/dV transposing reads

@@ -25,7 +25,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
 KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS, KNOB_LN_MULTI_CHUNK, KNOB_FLASH = 0, 1, 2, 3, 4, 5   # enum cmb_knob_id
-ABI_VERSION = 6   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
+ABI_VERSION = 7   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
           -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
@@ -125,6 +125,15 @@ class ImageJob(C.Structure):
     ]
 
 
+class PrepJob(C.Structure):
+    """cmb_prep_job (include/cambrian_amd.h): one weight of a cmb_weight_prep launch."""
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p), ("ld_src", C.c_int64),
+        ("src_dtype", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("rows_pad", C.c_int32),
+        ("tile0", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 # symbol -> (restype, argtypes); every symbol of include/cambrian_amd.h must be listed here
 # (tests/test_abi.py cross-checks this table against the header).
 _i32, _i64, _f, _p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -144,6 +153,9 @@ SIGNATURES = {
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
     "cmb_cast": (C.c_int, [C.c_int, _p, C.c_int, _p, _i64, _p]),
+    "cmb_weight_prep_tiles": (_i64, [_i64, _i64]),
+    "cmb_weight_prep_one": (C.c_int, [C.POINTER(PrepJob), _p]),
+    "cmb_weight_prep": (C.c_int, [_p, _i32, _i64, _p]),
     "cmb_layernorm_bwd_multi": (C.c_int, [C.POINTER(LnMultiDesc), _p]),
     "cmb_layernorm_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _p, _i64, _p, _p, _p]),
     "cmb_layernorm_bwd": (C.c_int, [C.c_int, _p, _i64, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _i64,

@@ -38,7 +38,21 @@ from .vision_sampler import VisionTokenSampler
 # static (fixed 2048-token layout, train) vs dynamic (eval/generate) path; replaces `IS_XLA_AVAILABLE`
 # (cambrian/utils.py:17-22) which cannot be the switch on a machine without torch_xla.
 STATIC_PATH = True
-_TOWER_STREAMS = os.environ.get("CAMBRIAN_AMD_TOWER_STREAMS", "0") == "1"   # opt-in: one HIP stream per frozen tower (encode_images)
+_TOWER_STREAMS = os.environ.get("CAMBRIAN_AMD_TOWER_STREAMS", "0")   # frozen towers on side HIP streams (encode_images)
+
+
+def _tower_stream_plan(n: int):
+    """CAMBRIAN_AMD_TOWER_STREAMS: "0" = every tower on the launch stream (None); "1" = one side stream per tower; else one
+    character per tower in list order — equal characters share a side stream (and run one after the other on it), "0" keeps
+    the tower on the launch stream, enqueued after the side streams' work."""
+    v = _TOWER_STREAMS
+    if v in ("", "0"):
+        return None
+    if v == "1":
+        return [chr(ord("a") + i) for i in range(n)]
+    if len(v) != n or set(v) == {"0"}:
+        return None
+    return list(v)
 
 
 @dataclass
@@ -255,21 +269,31 @@ class CambrianMetaForCausalLM(ABC):
         is therefore off by default."""
         towers = self.get_model().get_vision_tower_aux_list()
         frozen = all(not getattr(t, "unfreeze_mm_vision_tower", False) for t in towers)
-        if (not _TOWER_STREAMS or len(towers) < 2 or not frozen or not image_aux_list[0].is_cuda
+        plan = _tower_stream_plan(len(towers))
+        if (plan is None or len(towers) < 2 or not frozen or not image_aux_list[0].is_cuda
                 or torch.is_grad_enabled() and any(x.requires_grad for x in image_aux_list)):
             return [tower(image_aux) for image_aux, tower in zip(image_aux_list, towers)]
         main = torch.cuda.current_stream()
         pool = getattr(self, "_tower_streams", None)
-        if pool is None or len(pool) < len(towers):
-            pool = self._tower_streams = [torch.cuda.Stream() for _ in towers]
-        outs = []
-        for image_aux, tower, st in zip(image_aux_list, towers, pool):
+        if pool is None:
+            pool = self._tower_streams = {}
+        outs = [None] * len(towers)
+        used = []
+        for key in sorted(set(plan) - {"0"}):         # side streams first (each runs its towers in list order) ...
+            st = pool.get(key)
+            if st is None:
+                st = pool[key] = torch.cuda.Stream()
             st.wait_stream(main)                      # the images (and whatever produced them) are ready
             with torch.cuda.stream(st):
-                o = tower(image_aux)
-            o.record_stream(main)                     # allocated from st's pool, consumed on the main stream
-            outs.append(o)
-        for st in pool[:len(towers)]:
+                for i, k in enumerate(plan):
+                    if k == key:
+                        outs[i] = towers[i](image_aux_list[i])
+                        outs[i].record_stream(main)   # allocated from st's pool, consumed on the main stream
+            used.append(st)
+        for i, k in enumerate(plan):                  # ... then the towers that stay on the launch stream
+            if k == "0":
+                outs[i] = towers[i](image_aux_list[i])
+        for st in used:
             main.wait_stream(st)
         return outs
 
@@ -293,6 +317,8 @@ class CambrianMetaForCausalLM(ABC):
         image_token_len = cfg.image_token_len
         side = int(image_token_len ** 0.5)
         span = ops.region_begin("towers_connector")                                 # (bench.py roofline.region)
+        if torch.is_grad_enabled():
+            ops.weight_step_begin()    # bf16 copies of the trainable weights: one launch per step (closed by the model's forward)
         feats_raw = self.encode_images(image_aux_list)                              # :366
 
         sva_ctx = None

@@ -468,8 +468,11 @@ class CambrianLlamaForCausalLM(nn.Module, CambrianMetaForCausalLM):
         """``config.fp8_projections`` (BASELINE configs[4]): the forward GEMMs of the SVA-side projections — aux
         projectors, connector and in-LLM SVA layers, mm_projector, i.e. everything that goes through ``ops.linear`` —
         run on the fp8 MFMA with row-wise e4m3 scaling; towers and decoder are untouched, the backward stays bf16."""
-        with ops.fp8_projections(bool(getattr(self.config, "fp8_projections", False))):
-            return self._forward(*args, **kwargs)
+        try:
+            with ops.fp8_projections(bool(getattr(self.config, "fp8_projections", False))):
+                return self._forward(*args, **kwargs)
+        finally:
+            ops.weight_step_end()   # (the window prepare_inputs_labels_for_multimodal opened for this forward's linears)
 
     def _forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                  labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None,

@@ -556,6 +556,109 @@ def k_sva_attn_bwd(dout, q, kvs, masks, r_list, out, lse, B, qside, heads, hd, w
 
 
 # ================================================================================================
+# prepared weights: bf16 copy + transposed bf16 copy of the trainable 2-D weights, refreshed in ONE launch per step
+# ================================================================================================
+# Round 5 cast every fp32 master per use (cmb_cast in LinearFn.forward: 171 launches per step) and transposed it again per
+# backward (cmb_transpose for dx = g W: 166 launches) — 3.1 ms of 5-12 us kernels per step.  The model now opens a window per
+# training forward (weight_step_begin / weight_step_end): begin() refreshes the copies of every weight registered so far with
+# one cmb_weight_prep launch (one pass over the masters), the linears inside the window take them from the cache (a weight
+# seen for the first time is prepared on the spot and registered), the backward uses what the forward captured.  Outside a
+# window (direct calls of a layer, the re-computation forward of activation checkpointing, eval) nothing is cached: weights
+# may have changed in ways no version counter shows (ZeRO-2 writes the all-gathered shards straight into the flat buckets).
+# CAMBRIAN_AMD_PREP_WEIGHTS=0 restores the per-use launches (A/B runs).
+PREP_WEIGHTS = os.environ.get("CAMBRIAN_AMD_PREP_WEIGHTS", "1") != "0"
+_PREP: dict = {}
+_PREP_EPOCH = 0
+_PREP_ACTIVE = False
+_PREP_TABLE = None   # (signature, device job table, n_jobs, total_tiles)
+
+
+class _PrepEntry:
+    __slots__ = ("ref", "off", "shape", "stride", "w_c", "w_t", "rows_pad", "epoch", "src_ptr")
+
+
+def _prep_src_ptr(base: torch.Tensor, e: "_PrepEntry") -> int:
+    return base.data_ptr() + (e.off - base.storage_offset()) * base.element_size()
+
+
+def _prep_job(e: "_PrepEntry", base: torch.Tensor, tile0: int) -> "L.PrepJob":
+    j = L.PrepJob()
+    j.src, j.dst, j.dst_t = _prep_src_ptr(base, e), e.w_c.data_ptr(), e.w_t.data_ptr()
+    j.ld_src, j.src_dtype = e.stride[0], L.dtype_code(base.dtype)
+    j.rows, j.cols, j.rows_pad, j.tile0, j.reserved = e.shape[0], e.shape[1], e.rows_pad, tile0, 0
+    return j
+
+
+def weight_step_begin() -> None:
+    """Open the prepared-weight window of a training forward and refresh every registered weight's copies in one launch."""
+    global _PREP_EPOCH, _PREP_ACTIVE, _PREP_TABLE
+    if not PREP_WEIGHTS:
+        return
+    _PREP_EPOCH += 1
+    _PREP_ACTIVE = True
+    live = []
+    for key in list(_PREP):
+        e = _PREP[key]
+        base = e.ref()
+        if base is None or not base.is_cuda:
+            del _PREP[key]
+            continue
+        live.append((key, e, base))
+    if not live:
+        return
+    dev = live[0][2].device
+    sig = (dev, tuple((key, _prep_src_ptr(base, e), e.w_c.data_ptr()) for key, e, base in live))
+    if _PREP_TABLE is None or _PREP_TABLE[0] != sig:
+        jobs = (L.PrepJob * len(live))()
+        tile0 = 0
+        lib = L.load()
+        for i, (key, e, base) in enumerate(live):
+            jobs[i] = _prep_job(e, base, tile0)
+            tile0 += lib.cmb_weight_prep_tiles(e.rows_pad, e.shape[1])
+        table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        _PREP_TABLE = (sig, table, len(live), tile0)
+    _, table, n, tiles = _PREP_TABLE
+    L.check(L.load().cmb_weight_prep(table.data_ptr(), n, tiles, L.stream_ptr(dev)), "cmb_weight_prep")
+    for key, e, base in live:
+        e.epoch, e.src_ptr = _PREP_EPOCH, _prep_src_ptr(base, e)
+
+
+def weight_step_end() -> None:
+    global _PREP_ACTIVE
+    _PREP_ACTIVE = False
+
+
+def prepared_weight(weight: torch.Tensor, dt: torch.dtype):
+    """(bf16 copy [N, K], transposed bf16 copy [K, pad64(N)]) of a trainable weight inside a prepared-weight window, else None.
+    Only nn.Parameters (or views of one) qualify: their identity is what the cache is keyed on."""
+    if not (_PREP_ACTIVE and dt == torch.bfloat16 and weight.is_cuda and weight.dim() == 2 and weight.stride(1) == 1):
+        return None
+    base = weight._base if weight._base is not None else weight
+    if not isinstance(base, torch.nn.Parameter) or base.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    N, K = weight.shape
+    if K % 8 or weight.stride(0) % 8 or weight.data_ptr() % 16:
+        return None
+    key = (id(base), weight.storage_offset(), (N, K), tuple(weight.stride()))
+    e = _PREP.get(key)
+    if e is not None and e.ref() is not base:
+        e = None   # the id was recycled
+    if e is None:
+        import weakref
+        e = _PrepEntry()
+        e.ref = weakref.ref(base)
+        e.off, e.shape, e.stride, e.rows_pad, e.epoch, e.src_ptr = weight.storage_offset(), (N, K), tuple(weight.stride()), pad_to(N, 64), -1, 0
+        e.w_c = torch.empty((N, K), dtype=torch.bfloat16, device=weight.device)
+        e.w_t = torch.empty((K, e.rows_pad), dtype=torch.bfloat16, device=weight.device)
+        _PREP[key] = e
+    if e.epoch != _PREP_EPOCH or e.src_ptr != weight.data_ptr():   # first sight in this window: prepare it on the spot
+        j = _prep_job(e, base, 0)
+        L.check(L.load().cmb_weight_prep_one(C.byref(j), L.stream_ptr(weight.device)), "cmb_weight_prep_one")
+        e.epoch, e.src_ptr = _PREP_EPOCH, weight.data_ptr()
+    return e.w_c, e.w_t
+
+
+# ================================================================================================
 # autograd: linear
 # ================================================================================================
 # CAMBRIAN_AMD_TN_WGRAD=0: weight gradients through transposed copies + the NT kernels (A/B runs, tests of the old path)
@@ -600,7 +703,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act: int, residual, res_rep: int, colscale, heavy: bool = False):
         dt = x.dtype
-        w_c = k_cast(weight, dt)
+        prep = prepared_weight(weight, dt)
+        w_c, ctx.w_t = prep if prep is not None else (k_cast(weight, dt), None)
         b_c = None if bias is None else k_cast(bias, torch.float32)
         need_pre = act != L.ACT_NONE and (x.requires_grad or weight.requires_grad
                                           or (bias is not None and bias.requires_grad))
@@ -651,7 +755,7 @@ class LinearFn(torch.autograd.Function):
         ks = _kstep(dt)
         if need_x:
             n_pad = pad_to(N, ks)
-            w_t = k_transpose(w_c, n_pad)  # [K, N_pad]
+            w_t = ctx.w_t if (ctx.w_t is not None and ctx.w_t.shape[1] == n_pad) else k_transpose(w_c, n_pad)  # [K, N_pad]
             if n_pad != N:
                 gpad = torch.zeros((M, n_pad), dtype=dt, device=g.device)
                 gpad[:, :N] = g

@@ -66,7 +66,7 @@ const char* cmb_version(void);
  * the kernel-selection knobs of round 4 = 5).  Bindings must compare it with the revision they
  * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
  * library still resolves, and a shifted argument list corrupts memory instead of failing. */
-#define CMB_ABI_VERSION 6
+#define CMB_ABI_VERSION 7
 int cmb_abi_version(void);
 
 /* Run-time kernel-selection knobs: which of several kernels that compute the SAME function an entry point launches
@@ -79,6 +79,9 @@ int cmb_abi_version(void);
  *   CMB_KNOB_DWCONV     cmb_dwconv7x7_nhwc (C % 64 == 0): 0 = LDS-tiled kernel (rounds 1-3); 1 = column-walking kernel with
  *                       register-resident taps, 64 rows per chunk for maps of >= 128 rows, else 32; > 1 = that many rows per chunk
  *   CMB_KNOB_VIT_ATTN   cmb_vit_attn_fwd (bf16): 0 = two barriers per key tile (round 3); 1 = two LDS tile buffers, one barrier
+ *                       (both: register-staged K / V tiles, bit-identical); 2 = round 6: K / V tiles by LDS-DMA into swizzled
+ *                       images, V by transposing reads, lazy rescale, XCD-grouped 1-D grid, 128 queries per workgroup; 3 = the
+ *                       same with 256 queries per workgroup (2 / 3 agree with 0 / 1 to bf16 rounding, not bit for bit)
  *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
  *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
  *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 7 (one wave per SIMD) or 4 (two)
@@ -89,7 +92,7 @@ int cmb_abi_version(void);
  *                       profiles/r05_lab.md).  dQ / dK / dV are bit-identical across variants, the forward to fp32 rounding */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
                    CMB_KNOB_FLASH = 5, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 1, 1, 1, 0, 4, 23, 0, 0
+#define CMB_KNOB_DEFAULTS 1, 1, 2, 0, 4, 23, 0, 0
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 
@@ -186,6 +189,26 @@ int cmb_colsum(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in,
 
 /* y = (T)x elementwise casts between fp32 and bf16 (n elements). to_dtype/from_dtype are CMB_*. */
 int cmb_cast(int from_dtype, const void* in, int to_dtype, void* out, int64_t n, void* stream);
+
+/* Weight preparation: bf16 copy [rows, cols] (dst, row stride cols) and transposed bf16 copy [cols, rows_pad] (dst_t, zero
+ * columns rows .. rows_pad - 1) of a 2-D weight (fp32 master or bf16; row stride ld_src) — what the linears of
+ * vision_sampler.py:170-175,254-259 and cambrian_arch.py:49-56 need per step in bf16 compute: W for y = x W^T, W^T for
+ * dx = g W.  cmb_weight_prep takes a table of jobs in DEVICE memory (tile0 = prefix sum of cmb_weight_prep_tiles over the
+ * jobs before it) and covers every job in ONE launch; cmb_weight_prep_one takes one job by value (host memory).  Either
+ * output pointer may be NULL.  cols, rows_pad, ld_src multiples of 8; 16-byte aligned pointers. */
+typedef struct cmb_prep_job {
+  const void* src;
+  void* dst;
+  void* dst_t;
+  int64_t ld_src;
+  int32_t src_dtype; /* CMB_F32 | CMB_BF16 */
+  int32_t rows, cols, rows_pad;
+  int32_t tile0;
+  int32_t reserved;
+} cmb_prep_job;
+int64_t cmb_weight_prep_tiles(int64_t rows_pad, int64_t cols);
+int cmb_weight_prep_one(const cmb_prep_job* job, void* stream);
+int cmb_weight_prep(const cmb_prep_job* jobs_device, int32_t n_jobs, int64_t total_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm   y[r,:] = (x[r,:] (+ add[pos(r),:]) - mean) * rstd (* gamma + beta)

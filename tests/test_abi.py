@@ -112,7 +112,7 @@ def test_knob_values_are_validated(built):
     try:
         assert lib.cmb_knob_set(built.KNOB_DWCONV, -3) == bad
         assert lib.cmb_knob_set(built.KNOB_LN_FWD, -1) == bad
-        assert lib.cmb_knob_set(built.KNOB_VIT_ATTN, 2) == bad
+        assert lib.cmb_knob_set(built.KNOB_VIT_ATTN, 4) == bad
         assert lib.cmb_knob_set(built.KNOB_SVA_ABS, 7) == bad
         assert lib.cmb_knob_set(built.KNOB_LN_MULTI_CHUNK, 5) == bad
         assert lib.cmb_knob_set(99, 0) == bad

@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["gemm_tn_layout_sim", "sva_abs_layout_sim", "flash_layout_sim"])
+@pytest.mark.parametrize("name", ["gemm_tn_layout_sim", "sva_abs_layout_sim", "flash_layout_sim", "vit_layout_sim"])
 def test_layout_simulation(name):
     src = os.path.join(ROOT, "tests", "csrc", name + ".cpp")
     with tempfile.TemporaryDirectory() as d:

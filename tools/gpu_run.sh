@@ -70,6 +70,15 @@ P
       for k in "$@"; do python tools/pmc_sq_summarise.py $P $k | tee -a $O/pmc_flash_$TAG.jsonl | cut -c1-1500; done
       rm -rf $P
       ;;
+    pmcsq)   # SQ counter passes (separate --pmc runs, --kernel-trace only) of any command: pmcsq <tag> <kernel substring> <command...>
+      local tag=$1 ksub=$2; shift 2
+      local P=$GRAFT_REPO_ROOT/$O/pmc_$tag; mkdir -p $P
+      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $P/sq -o sq -- "$@" > $P/sq.log 2>&1
+        timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $P/sq2 -o sq2 -- "$@" > $P/sq2.log 2>&1
+        timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU --output-format csv -d $P/sq3 -o sq3 -- "$@" > $P/sq3.log 2>&1 )
+      python tools/pmc_sq_summarise.py $P "$ksub" | tee -a $O/pmc_sq_$tag.jsonl | cut -c1-2500
+      tail -3 $P/sq.log; rm -rf $P   # (the command runs from /tmp: give it absolute paths)
+      ;;
     py) timeout 1200 python "$@" 2>&1 | tail -60 ;;
     *) echo "unknown verb $verb"; return 2 ;;
   esac

@@ -24,6 +24,8 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--images", type=int, default=24)
 ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06", "lab.jsonl"))
 ap.add_argument("--tag", default="")
+ap.add_argument("--variant", type=int, default=2)
+ap.add_argument("--tower", default="DINOv2")
 args = ap.parse_args()
 B = args.images
 dev = torch.device("cuda", 0)
@@ -112,7 +114,7 @@ if "attn" in verbs:
         hdp = 96 if hd == 72 else hd
         qkv = rn(B * N, 3 * heads * hdp, scale=1.0)
         fns, ref, same = {}, None, {}
-        for var in (0, 1, 2):
+        for var in (0, 1, 2, 3):
             try:
                 L.knob_set(L.KNOB_VIT_ATTN, var)
             except Exception:
@@ -142,3 +144,13 @@ if "tn" in verbs:
         emit(case="tn", shape=f"dW {name} from {R} rows", us={k: round(v, 1) for k, v in us.items()},
              tflops={k: round(2.0 * R * n_out * k_in / v / 1e6) for k, v in us.items()}, auto_split=ops._tn_splits(n_out, k_in, R))
         del g, x
+
+if "attnone" in verbs:   # a few launches of ONE variant at ONE tower's shape: the workload of the rocprofv3 --pmc passes
+    from cambrian_amd.model.multimodal_encoder import vit_ops as V
+    name, N, heads, hd = {"CLIP": ("CLIP", 577, 16, 64), "DINOv2": ("DINOv2", 730, 24, 64), "SigLIP": ("SigLIP", 729, 16, 72)}[args.tower]
+    hdp = 96 if hd == 72 else hd
+    qkv = rn(B * N, 3 * heads * hdp)
+    L.knob_set(L.KNOB_VIT_ATTN, args.variant)
+    for _ in range(6):
+        V.k_vit_attn(qkv, B, N, heads, hdp, hd ** -0.5)
+    torch.cuda.synchronize()
