@@ -723,6 +723,7 @@ def main():
         cfg.fused_loss = "scored_rows"
     params = [p for p in model.parameters() if p.requires_grad]
     z3_units = None
+    lr = 4e-5 if args.stage == "finetune" else 1e-4   # one constant per stage, whatever shards the state (scripts/cambrian/finetune_cambrian_8b.sh: 4e-5)
     if args.zero3:
         # XLA-FSDP full_shard of the reference (fsdp_config.json: transformer_layer_cls_to_wrap = the decoder layer):
         # one unit per decoder layer — 97 % of a 34 B model's parameters; frozen in this stage, so sharded for memory
@@ -735,19 +736,22 @@ def main():
         in_units = {id(p) for mod in mods for p in mod.parameters()}
         z3_units = zero3_wrap(mods, gradient_checkpointing=bool(cfg.gradient_checkpointing))
         rest = [p for p in params if id(p) not in in_units]
-        opt = torch.optim.AdamW(zero3_parameters(z3_units) + rest, lr=1e-4, weight_decay=0.0, fused=True)
+        # the units' shards are fp32 masters already; whatever trains outside them in a narrower type (finetune stage:
+        # embed_tokens / lm_head in bf16) gets an fp32 master here too (they were stepped in bf16)
+        from cambrian_amd.train.master import MasterAdamW
+        opt = MasterAdamW(zero3_parameters(z3_units) + rest, lr=lr, weight_decay=0.0)
         sync = GradSync(rest, bucket_mb=args.bucket_mb) if rest else None
     elif args.zero2:
         from cambrian_amd.train.zero import Zero2AdamW
-        opt, sync = Zero2AdamW(params, lr=1e-4, weight_decay=0.0, bucket_mb=args.bucket_mb), None
+        opt, sync = Zero2AdamW(params, lr=lr, weight_decay=0.0, bucket_mb=args.bucket_mb), None
     elif args.stage == "finetune":
         # fp32 masters + fp32 moments for the bf16 decoder (the reference: fp32 FSDP parameters, bf16 compute —
         # train_fsdp.py:1324-1326, fsdp_config.json:6): 16 B per parameter; ZeRO-2 / ZeRO-3 above shard the same state
         from cambrian_amd.train.master import MasterAdamW
-        opt = MasterAdamW(params, lr=4e-5, weight_decay=0.0)
+        opt = MasterAdamW(params, lr=lr, weight_decay=0.0)
         sync = GradSync(params, bucket_mb=args.bucket_mb)
     else:
-        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.0, fused=True)
+        opt = torch.optim.AdamW(params, lr=lr, weight_decay=0.0, fused=True)
         sync = GradSync(params, bucket_mb=args.bucket_mb)
     if args.comm_only:
         return comm_only(args, rank, world, dev, params, opt, sync)
@@ -960,8 +964,11 @@ def main():
             line["config"]["workload"] = line["config"]["workload"].replace(
                 "pre-training stage (SVA+projectors train, LLM+towers frozen)", "FINETUNE stage (LLM + SVA + projectors train, towers frozen)")
             line["config"]["trainable_parameters"] = int(sum(p.numel() for p in params))
-            line["config"]["optimizer_state"] = ("fp32 master weights + fp32 AdamW moments for the bf16 decoder (16 B / parameter"
-                                                 + (", sharded 1 / world" if (args.zero2 or args.zero3) else "") + "), lr 4e-5")
+            n_low = sum(p.numel() for p in params if p.dtype != torch.float32)
+            line["config"]["optimizer_state"] = (
+                f"{type(opt).__name__}, lr {lr:g}: fp32 master weights + fp32 AdamW moments for every trainable parameter that "
+                f"computes in bf16 ({n_low / 1e9:.2f} B parameters; 16 B / parameter"
+                + (", sharded 1 / world" if (args.zero2 or args.zero3) else "") + ")")
             line["config"]["gradient_buckets"] = (len(sync.buckets) if sync is not None else len(getattr(opt, "buckets", [])))
         if cfg.gradient_checkpointing:
             line["config"]["activation_recomputation"] = "decoder layers + in-LLM SVA layers (non-reentrant checkpoint)"

@@ -648,7 +648,7 @@ extern "C" int cmb_knob_set(int32_t knob, int32_t value) {
     case CMB_KNOB_VIT_ATTN: ok = value >= 0 && value <= 3; break;              // 2 = LDS-DMA tiles + transposing reads (round 6)
     case CMB_KNOB_SVA_ABS: ok = value == 0 || value == 1; break;
     case CMB_KNOB_LN_MULTI_CHUNK: ok = value == 4 || value == 7; break;
-    case CMB_KNOB_FLASH: ok = value >= 0 && value <= 31; break;   // bit mask: 1 forward, 2 dQ, 4 dK/dV body, 8 dK/dV tiles, 16 dK/dV transposing reads
+    case CMB_KNOB_FLASH: ok = value >= 0 && value <= 31 && !(value & 8); break;   // bit mask: 1 forward, 2 dQ, 4 dK/dV body, 16 dK/dV transposing reads (8: removed)
     default: ok = value >= 0; break;
   }
   if (!ok) return CMB_ERR_BAD_ARG;

@@ -339,7 +339,6 @@ __global__ void __launch_bounds__(256, 2) flash_dq2_kernel(const FlashParams p) 
       if (g == 0) p.dvec[st] = dq_d;
     }
     float lse2 = p.lse[st] * LOG2E;
-    if (g == 0) p.dvec[(int64_t)p.B * p.H * p.S + st] = lse2;   // second half of dvec: what flash_dkdv2_kernel exponentiates against
     // every prologue load is awaited here, not by stale vmcnt waits inside the tile loop (see flash_fwd2_kernel)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
@@ -463,273 +462,9 @@ __global__ void __launch_bounds__(256, 2) flash_dq2_kernel(const FlashParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// dK, dV on the same operand tiles.  A workgroup owns 128 keys of one (batch, KV head), a LANE owns a key (K, V fragments in
-// registers) and walks the 64-query tiles of the group's query heads from the diagonal on: S = Q K^T and dP = dO V^T from
-// row-major fragments of the Q / dO tiles, dV^T += dO^T P and dK^T += Q^T dS with the transposed fragments read out of the SAME
-// two tiles (flash_dkdv_kernel keeps four images — Q, dO, Q^T, dO^T — written through registers: 32 ds_write_b128 + 64
-// ds_write_b32 + ~150 vector instructions per tile and thread).  The log-sum-exp (already x log2 e) and D rows of a tile arrive
-// by LDS-DMA as well (the dQ kernel of this file writes both into dvec: [0, BHS) D, [BHS, 2 BHS) lse x log2 e).  One barrier per
-// tile, Q / dO double-buffered.  Interior tiles run flash_dkdv_kernel's round-5 four-phase body (every MFMA followed by the
-// fragment read four products ahead and one element of the other half's softmax), diagonal / padded tiles the plain order.
-// Lane <-> element arrangement, products and accumulation order are flash_dkdv_kernel's: bit-identical results.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int kSmemDkdv = 4 * kTile + 2 * 512;
-
-__device__ __forceinline__ void dma_dword(const char* base, uint32_t voff, uint32_t lds) {   // 64 lanes x 4 bytes, lane-linear
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"
-               :
-               : "v"(voff), "s"(base), "s"(lds)
-               : "memory", "m0");
-}
-
-template <bool CAUSAL, bool MASKED>
-__global__ void __launch_bounds__(256) flash_dkdv2_kernel(const FlashParams p) {
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 5, j = lane & 31;
-  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem));
-  const int nkb = p.S / 128;
-  const FlashBlock fb = flash_block_kv((int)blockIdx.x, (int)gridDim.x, flash_items(nkb, CAUSAL), p.HKV);
-  const int b = fb.b, hk = fb.hk;
-  const int nrep = flash_pair_count(nkb, fb.blk, CAUSAL);
-  const int group = p.H / p.HKV;
-  const float c2 = p.scale * LOG2E;
-  const int64_t bhs = (int64_t)p.B * p.H * p.S;
-  uint32_t voff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = 4 * wave + i;
-    voff[i] = (uint32_t)(fl_dma_row(piece, lane) * (int)(p.q_ss * 2) + fl_dma_src_slot(piece, lane) * 16);
-  }
-  uint32_t kro[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kro[ks] = (uint32_t)fl_row_frag_off(0, ks, lane);
-  uint32_t tro[DT][2];
-#pragma unroll
-  for (int d = 0; d < DT; ++d)
-#pragma unroll
-    for (int r = 0; r < 2; ++r) tro[d][r] = (uint32_t)fl_tr_frag_off(0, 32 * d, r, lane);
-
-  for (int rep = 0; rep < nrep; ++rep) {
-    const int kb = flash_pair_k(nkb, fb.blk, rep, CAUSAL);
-    const int k0 = kb * 128 + wave * 32;
-    const int ki = k0 + j;
-    const bf16_t* krow = p.k + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
-    const bf16_t* vrow = p.v + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
-    bf16x8_t kf[KS], vf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      kf[ks] = *reinterpret_cast<const bf16x8_t*>(krow + ks * 16 + g * 8);
-      vf[ks] = *reinterpret_cast<const bf16x8_t*>(vrow + ks * 16 + g * 8);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // awaited here (see flash_fwd2_kernel)
-    // key-padding mask: this lane's key is padded -> only its own query (the open diagonal) contributes
-    const bool kvalid = !MASKED || p.key_valid[(int64_t)b * p.S + ki] != 0;
-    const bool wave_padded = MASKED && __builtin_amdgcn_ballot_w64(!kvalid) != 0;
-    f32x16_t adk[DT], adv[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { adk[d][r] = 0.f; adv[d][r] = 0.f; }
-    const int qt0 = CAUSAL ? (kb * 128) / 64 : 0, nq = p.S / 64 - qt0, NT = group * nq;
-
-    auto issue = [&](int n) {   // tile n = (query head n / nq of the group, query tile qt0 + n % nq) -> buffers n & 1
-      const int hq = n / nq, qt = qt0 + (n - hq * nq), h = hk * group + hq;
-      const int64_t eoff = (int64_t)b * p.q_sb + (int64_t)h * p.q_sh + (int64_t)(qt * 64) * p.q_ss;
-      const char* qs_ = uniform_ptr(reinterpret_cast<const char*>(p.q + eoff));
-      const char* gs_ = uniform_ptr(reinterpret_cast<const char*>(p.dout + eoff));
-      const uint32_t qd = lds0 + (uint32_t)((n & 1) * kTile) + (uint32_t)wave * 4096u;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma_piece(qs_, voff[i], qd + (uint32_t)i * 1024u);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dma_piece(gs_, voff[i], qd + (uint32_t)(2 * kTile) + (uint32_t)i * 1024u);
-      if (wave < 2) {   // wave 0: 64 x (lse x log2 e), wave 1: 64 x D
-        const int64_t st = ((int64_t)b * p.H + h) * p.S + qt * 64 + (wave == 0 ? bhs : 0);
-        const char* ls_ = uniform_ptr(reinterpret_cast<const char*>(p.dvec + st));
-        dma_dword(ls_, (uint32_t)lane * 4u, lds0 + (uint32_t)(4 * kTile + (n & 1) * 512 + wave * 256));
-      }
-    };
-    __syncthreads();
-    issue(0);
-    for (int n = 0; n < NT; ++n) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (n + 1 < NT) issue(n + 1);
-      const int hq_ = n / nq, qt = qt0 + (n - hq_ * nq);
-      if (CAUSAL && qt * 64 + 63 < k0) continue;  // every query of the tile precedes this wave's keys
-      const char* tq = smem + (n & 1) * kTile;
-      const char* tg = tq + 2 * kTile;
-      const float* sLse = reinterpret_cast<const float*>(smem + 4 * kTile + (n & 1) * 512);
-      const float* sD = sLse + 64;
-      // product i = 2 ks + w of a score phase of half qs: w = 0 S (Q rows x K fragment), w = 1 dP (dO rows x V fragment)
-      auto row_frag = [&](int qs, int i) __attribute__((always_inline)) -> bf16x8_t {
-        return *reinterpret_cast<const bf16x8_t*>(((i & 1) ? tg : tq) + kro[i >> 1] + qs * 32 * FL_ROW_BYTES);
-      };
-      // product i = 8 qb16 + 2 d + w of a gradient phase: w = 0 dV (dO^T rows of d tile d), w = 1 dK (Q^T rows); read r
-      auto tr_frag = [&](int qs, int i, int r) __attribute__((always_inline)) -> s16x4_t {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_tr_ptr)(((i & 1) ? tq : tg) + tro[(i >> 1) & 3][r] + (qs * 32 + 16 * (i >> 3)) * FL_ROW_BYTES));
-      };
-      f32x4_t lq[4], dq4[4];
-      auto load_ld = [&](int qs) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          lq[r4] = *reinterpret_cast<const f32x4_t*>(sLse + qs * 32 + 8 * r4 + 4 * g);
-          dq4[r4] = *reinterpret_cast<const f32x4_t*>(sD + qs * 32 + 8 * r4 + 4 * g);
-        }
-      };
-      // element r of a half: pr = P, s = dS = P (dP - D)
-      auto elem = [&](int r, f32x16_t& s_, const f32x16_t& dp_, f32x16_t& pr_) __attribute__((always_inline)) {
-        const float t = __builtin_fmaf(s_[r], c2, -lq[r >> 2][r & 3]);
-        pr_[r] = __builtin_amdgcn_exp2f(t);
-        const float u = dp_[r] - dq4[r >> 2][r & 3];
-        s_[r] = pr_[r] * u;
-      };
-      auto mfma_sdp = [&](int i, const bf16x8_t& f, f32x16_t& s_, f32x16_t& dp_) __attribute__((always_inline)) {
-        if (i == 0) s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, kf[0], (f32x16_t){0}, 0, 0, 0);
-        else if (i == 1) dp_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, vf[0], (f32x16_t){0}, 0, 0, 0);
-        else if (i & 1) dp_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, vf[i >> 1], dp_, 0, 0, 0);
-        else s_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, kf[i >> 1], s_, 0, 0, 0);
-      };
-      auto mfma_grad = [&](int i, const s16x4_t& lo, const s16x4_t& hi, const u32x4_v (&pf)[2], const u32x4_v (&dsf)[2])
-          __attribute__((always_inline)) {
-        const s16x8_t tv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int d = (i >> 1) & 3;
-        if (i & 1) adk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, tv),
-                                                                     __builtin_bit_cast(bf16x8_t, dsf[i >> 3]), adk[d], 0, 0, 0);
-        else adv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, tv),
-                                                               __builtin_bit_cast(bf16x8_t, pf[i >> 3]), adv[d], 0, 0, 0);
-      };
-      auto pack = [&](const f32x16_t& pr_, const f32x16_t& s_, u32x4_v (&pf)[2], u32x4_v (&dsf)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int h8 = 0; h8 < 2; ++h8)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            pf[h8][c] = cvt2(pr_[8 * h8 + 2 * c], pr_[8 * h8 + 2 * c + 1]);
-            dsf[h8][c] = cvt2(s_[8 * h8 + 2 * c], s_[8 * h8 + 2 * c + 1]);
-          }
-      };
-      // mask only where some key of the wave can be masked for some query of a 32-row half tile
-      const bool edge0 = (CAUSAL ? (k0 + 31 > qt * 64) : (k0 + 32 > p.kv_len)) || wave_padded;
-      const bool edge1 = (CAUSAL ? (k0 + 31 > qt * 64 + 32) : (k0 + 32 > p.kv_len)) || wave_padded;
-      if (!edge0 && !edge1) {
-        //   A  S0, dP0          B  S1, dP1  + P0, dS0 (element i per product)          C  dV0, dK0  + P1, dS1          D  dV1, dK1
-        f32x16_t s0, dp0, s1, dp1, pr0, pr1;
-        bf16x8_t rf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rf[i] = row_frag(0, i);
-        FL_FENCE();
-#pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) {   // A
-          mfma_sdp(i, rf[i & 3], s0, dp0);
-          rf[i & 3] = row_frag(i + 4 < 2 * KS ? 0 : 1, (i + 4) & (2 * KS - 1));   // runs on into phase B's first four
-          FL_FENCE();
-        }
-        load_ld(0);
-        FL_FENCE();
-#pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) {   // B
-          mfma_sdp(i, rf[i & 3], s1, dp1);
-          if (i + 4 < 2 * KS) rf[i & 3] = row_frag(1, i + 4);
-          elem(i, s0, dp0, pr0);
-          FL_FENCE();
-        }
-        u32x4_v pf[2], dsf[2];
-        pack(pr0, s0, pf, dsf);
-        load_ld(1);
-        s16x4_t tlo[4], thi[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          tlo[i] = tr_frag(0, i, 0);
-          thi[i] = tr_frag(0, i, 1);
-        }
-        FL_FENCE();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {   // C
-          mfma_grad(i, tlo[i & 3], thi[i & 3], pf, dsf);
-          tlo[i & 3] = tr_frag(i + 4 < 16 ? 0 : 1, (i + 4) & 15, 0);   // runs on into phase D's first four
-          thi[i & 3] = tr_frag(i + 4 < 16 ? 0 : 1, (i + 4) & 15, 1);
-          elem(i, s1, dp1, pr1);
-          FL_FENCE();
-        }
-        pack(pr1, s1, pf, dsf);
-        FL_FENCE();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {   // D
-          mfma_grad(i, tlo[i & 3], thi[i & 3], pf, dsf);
-          if (i + 4 < 16) {
-            tlo[i & 3] = tr_frag(1, i + 4, 0);
-            thi[i & 3] = tr_frag(1, i + 4, 1);
-          }
-          FL_FENCE();
-        }
-      } else {
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-          f32x16_t s_, dp_, pr_;
-          bf16x8_t rf[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) rf[i] = row_frag(qs, i);
-#pragma unroll
-          for (int i = 0; i < 2 * KS; ++i) {
-            mfma_sdp(i, rf[i & 3], s_, dp_);
-            if (i + 4 < 2 * KS) rf[i & 3] = row_frag(qs, i + 4);
-          }
-          load_ld(qs);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            pr_[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_[r], c2, -lq[r >> 2][r & 3]));
-            s_[r] = dp_[r] - dq4[r >> 2][r & 3];
-          }
-          if (qs == 0 ? edge0 : edge1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int qidx = qt * 64 + qs * 32 + 8 * (r >> 2) + 4 * g + (r & 3);
-              if (!(CAUSAL ? (ki <= qidx && (kvalid || ki == qidx)) : ki < p.kv_len)) pr_[r] = 0.f;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s_[r] = pr_[r] * s_[r];
-          u32x4_v pf[2], dsf[2];
-          pack(pr_, s_, pf, dsf);
-          s16x4_t tlo[4], thi[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            tlo[i] = tr_frag(qs, i, 0);
-            thi[i] = tr_frag(qs, i, 1);
-          }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            mfma_grad(i, tlo[i & 3], thi[i & 3], pf, dsf);
-            if (i + 4 < 16) {
-              tlo[i & 3] = tr_frag(qs, i + 4, 0);
-              thi[i & 3] = tr_frag(qs, i + 4, 1);
-            }
-          }
-        }
-      }
-    }
-    bf16_t* okr = p.dk + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
-    bf16_t* ovr = p.dv + (int64_t)b * p.kv_sb + (int64_t)ki * p.kv_ss + (int64_t)hk * p.kv_sh;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        bf16x4_t a, c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] = (bf16_t)(adk[d][4 * qd + e] * p.scale);
-          c[e] = (bf16_t)adv[d][4 * qd + e];
-        }
-        *reinterpret_cast<bf16x4_t*>(okr + d * 32 + 8 * qd + 4 * g) = a;
-        *reinterpret_cast<bf16x4_t*>(ovr + d * 32 + 8 * qd + 4 * g) = c;
-      }
-  }  // rep
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
+// (A dK / dV kernel on the same LDS-DMA tiles existed up to round 5 — flash_dkdv2_kernel, CMB_KNOB_FLASH bit 8, bit-identical and
+// ~200 us per layer SLOWER than flash_dkdv_kernel<..., PIPE, TR>: at 460 registers hipcc moved the accumulators between the
+// register halves every tile, profiles/r05_lab.md.  It was never the default and is removed in round 6: git history, commit a4e275e.)
 
 }  // namespace
 
@@ -776,26 +511,5 @@ int launch_flash_dq2(const FlashParams& p, bool causal, hipStream_t stream) {
   return CMB_OK;
 }
 
-
-int launch_flash_dkdv2(const FlashParams& p, bool causal, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    bool ok = true;
-#define DKDV2_ATTR(C_, M_)                                                                             \
-  ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv2_kernel<C_, M_>),             \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, kSmemDkdv) == hipSuccess
-    DKDV2_ATTR(true, true); DKDV2_ATTR(true, false); DKDV2_ATTR(false, false);
-#undef DKDV2_ATTR
-    if (!ok) return CMB_ERR_LAUNCH;
-    attr_done = true;
-  }
-  const int64_t nkb = p.S / 128;
-  const dim3 grid((unsigned)((int64_t)flash_items((int)nkb, causal) * p.HKV * p.B));
-  if (causal && p.key_valid) hipLaunchKernelGGL((flash_dkdv2_kernel<true, true>), grid, dim3(256), kSmemDkdv, stream, p);
-  else if (causal) hipLaunchKernelGGL((flash_dkdv2_kernel<true, false>), grid, dim3(256), kSmemDkdv, stream, p);
-  else hipLaunchKernelGGL((flash_dkdv2_kernel<false, false>), grid, dim3(256), kSmemDkdv, stream, p);
-  CMB_CHECK_LAUNCH();
-  return CMB_OK;
-}
 
 }  // namespace cmb_flash

@@ -895,20 +895,17 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
     if (!ok) return CMB_ERR_LAUNCH;
     attr_done = true;
   }
-  // knob bits: 2 = dQ on LDS-DMA tiles (flash2.hip), 8 = dK/dV on LDS-DMA tiles (flash2.hip; needs bit 2: that dQ kernel
-  // writes the second half of dvec), 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 0 = round 4
+  // knob bits: 2 = dQ on LDS-DMA tiles (flash2.hip), 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body,
+  // 16 = its transposed fragments by transposing reads; 0 = round 4  (bit 8, a dK/dV kernel on LDS-DMA tiles, is gone)
   const int knob = cmb_knob(CMB_KNOB_FLASH);
-  const bool pipe_q = (knob & 2) != 0, pipe_k = (knob & 4) != 0, k2 = (knob & 8) != 0 && pipe_q, tr_k = (knob & 16) != 0;
+  const bool pipe_q = (knob & 2) != 0, pipe_k = (knob & 4) != 0, tr_k = (knob & 16) != 0;
 #define FLASH_BWD_LAUNCH(C_, M_)                                                                      \
   do {                                                                                                \
     if (pipe_q) {                                                                                     \
       const int rc_ = launch_flash_dq2(p, C_, s);                                                     \
       if (rc_ != CMB_OK) return rc_;                                                                  \
     } else hipLaunchKernelGGL((flash_dq_kernel<C_, M_, false>), gq, dim3(256), 0, s, p);              \
-    if (k2) {                                                                                         \
-      const int rc_ = launch_flash_dkdv2(p, C_, s);                                                   \
-      if (rc_ != CMB_OK) return rc_;                                                                  \
-    } else if (pipe_k && tr_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, true, true>), gk, dim3(256), smem, s, p); \
+    if (pipe_k && tr_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, true, true>), gk, dim3(256), smem, s, p); \
     else if (pipe_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, true, false>), gk, dim3(256), smem, s, p); \
     else if (tr_k) hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, false, true>), gk, dim3(256), smem, s, p); \
     else hipLaunchKernelGGL((flash_dkdv_kernel<C_, M_, false, false>), gk, dim3(256), smem, s, p);    \

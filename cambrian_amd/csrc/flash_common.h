@@ -17,7 +17,7 @@ struct FlashParams {
   const bf16_t *q, *k, *v, *o, *dout;
   bf16_t *dq, *dk, *dv;
   const float* lse;  // [B, H, S]
-  float* dvec;       // [2, B, H, S]: [0] D = rowsum(dO * O); [1] lse * log2 e (written by flash_dq2_kernel for flash_dkdv2_kernel)
+  float* dvec;       // [2, B, H, S]: [0] D = rowsum(dO * O); [1] unused since round 6 (was lse * log2 e for the removed flash_dkdv2_kernel)
   int64_t q_sb, q_ss, q_sh;     // strides of q / o / do / dq (elements)
   int64_t kv_sb, kv_ss, kv_sh;  // strides of k / v / dk / dv
   int B, S, H, HKV;
@@ -50,7 +50,5 @@ __device__ __forceinline__ uint32_t flash_open_bits(uint64_t vw, int kt, int g, 
 int launch_flash_fwd2(const FlashParams& p, bf16_t* out, float* lse, bool causal, hipStream_t stream);
 // flash2.hip: dQ on the same tiles (knob bit 1); it also writes dvec (D = rowsum(dO o O)) for the dK/dV kernel
 int launch_flash_dq2(const FlashParams& p, bool causal, hipStream_t stream);
-// flash2.hip: dK / dV on the same tiles (knob bit 3; needs the dvec halves launch_flash_dq2 writes)
-int launch_flash_dkdv2(const FlashParams& p, bool causal, hipStream_t stream);
 
 }  // namespace cmb_flash

@@ -571,6 +571,7 @@ _PREP: dict = {}
 _PREP_EPOCH = 0
 _PREP_ACTIVE = False
 _PREP_TABLE = None   # (signature, device job table, n_jobs, total_tiles)
+_PREP_TMP: dict = {}   # id(tensor) -> (weakref, w_c, w_t): per-step weights made inside a window (the folded K|V weights)
 
 
 class _PrepEntry:
@@ -596,6 +597,7 @@ def weight_step_begin() -> None:
         return
     _PREP_EPOCH += 1
     _PREP_ACTIVE = True
+    _PREP_TMP.clear()
     live = []
     for key in list(_PREP):
         e = _PREP[key]
@@ -626,6 +628,23 @@ def weight_step_begin() -> None:
 def weight_step_end() -> None:
     global _PREP_ACTIVE
     _PREP_ACTIVE = False
+    _PREP_TMP.clear()
+
+
+def prepare_step_weight(w: torch.Tensor) -> None:
+    """A weight computed inside the window (fp32 [N, K], e.g. the folded K|V projection): its bf16 copy and transposed copy in
+    one launch, found by ``prepared_weight`` for ``w`` itself and for row slices of it (the absorbed tower's K / V halves)."""
+    if not (_PREP_ACTIVE and w.is_cuda and w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32 and w.shape[1] % 8 == 0):
+        return
+    import weakref
+    N, K = w.shape
+    w_c = torch.empty((N, K), dtype=torch.bfloat16, device=w.device)
+    w_t = torch.empty((K, pad_to(N, 64)), dtype=torch.bfloat16, device=w.device)
+    j = L.PrepJob()
+    j.src, j.dst, j.dst_t, j.ld_src, j.src_dtype = w.data_ptr(), w_c.data_ptr(), w_t.data_ptr(), K, L.F32
+    j.rows, j.cols, j.rows_pad, j.tile0, j.reserved = N, K, w_t.shape[1], 0, 0
+    L.check(L.load().cmb_weight_prep_one(C.byref(j), L.stream_ptr(w.device)), "cmb_weight_prep_one")
+    _PREP_TMP[id(w)] = (weakref.ref(w), w_c, w_t)
 
 
 def prepared_weight(weight: torch.Tensor, dt: torch.dtype):
@@ -634,6 +653,16 @@ def prepared_weight(weight: torch.Tensor, dt: torch.dtype):
     if not (_PREP_ACTIVE and dt == torch.bfloat16 and weight.is_cuda and weight.dim() == 2 and weight.stride(1) == 1):
         return None
     base = weight._base if weight._base is not None else weight
+    tmp = _PREP_TMP.get(id(base))
+    if tmp is not None and tmp[0]() is base:   # a weight made inside this window, or rows [r0, r1) of it
+        ldw = base.shape[1]
+        if weight is base:
+            return tmp[1], tmp[2]
+        off = weight.storage_offset() - base.storage_offset()
+        if weight.shape[1] == ldw and weight.stride(0) == ldw and off % ldw == 0:
+            r0 = off // ldw
+            return tmp[1][r0:r0 + weight.shape[0]], tmp[2][:, r0:r0 + weight.shape[0]]
+        return None
     if not isinstance(base, torch.nn.Parameter) or base.dtype not in (torch.float32, torch.bfloat16):
         return None
     N, K = weight.shape
@@ -1028,7 +1057,9 @@ def fold_kv(wk, gk, bk, wv, gv, bv):
     """Folded K|V weight / bias in fp32.  Parameters that are not fp32 masters (a module moved with ``.to(bfloat16)`` /
     ``.half()``) are up-cast by autograd-tracked ``.float()`` first, as the torch expression this replaces did."""
     ts = [t if t.dtype == torch.float32 else t.float() for t in (wk, gk, bk, wv, gv, bv)]
-    return FoldKVFn.apply(*ts)
+    w, b = FoldKVFn.apply(*ts)
+    prepare_step_weight(w)   # (inside a training window: the bf16 copies the consuming linears would otherwise make per use)
+    return w, b
 
 
 # ================================================================================================
@@ -1117,11 +1148,16 @@ class HeadExpandFn(torch.autograd.Function):
     def forward(ctx, x, w, heads: int):
         Bq, C = x.shape
         hd, Cin = C // heads, w.shape[1]
-        w_c = k_cast(w, x.dtype)
-        w_t = k_transpose(w_c, C)                                    # [Cin, C]: rows c, the head's 64 inputs contiguous
+        prep = prepared_weight(w, x.dtype)
+        if prep is not None and prep[1].shape[1] == C:
+            w_c, w_t = prep
+        else:
+            w_c = k_cast(w, x.dtype)
+            w_t = k_transpose(w_c, C)                                # [Cin, C]: rows c, the head's 64 inputs contiguous
         U = torch.empty((Bq, heads, Cin), dtype=x.dtype, device=x.device)
         xc = x if x.is_contiguous() else x.contiguous()
-        k_gemm_batched(xc, w_t, U, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=C, ldc=heads * Cin, a_bs=hd, b_bs=hd, c_bs=Cin)
+        k_gemm_batched(xc, w_t, U, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=w_t.stride(0), ldc=heads * Cin, a_bs=hd, b_bs=hd,
+                       c_bs=Cin)
         ctx.save_for_backward(xc, w_c)
         ctx.heads, ctx.w_dtype = heads, w.dtype
         return U
@@ -1155,7 +1191,8 @@ class HeadContractFn(torch.autograd.Function):
         Bq, H, Cin = xb.shape
         C = w.shape[0]
         hd = C // heads
-        w_c = k_cast(w, xb.dtype)
+        prep = prepared_weight(w, xb.dtype)
+        w_c, ctx.w_t = prep if (prep is not None and prep[1].shape[1] == C) else (k_cast(w, xb.dtype), None)
         xbc = xb if xb.is_contiguous() else xb.contiguous()
         y = torch.empty((Bq, C), dtype=xb.dtype, device=xb.device)
         k_gemm_batched(xbc, w_c, y, batch=heads, M=Bq, N=hd, K=Cin, lda=heads * Cin, ldb=Cin, ldc=C, a_bs=Cin,
@@ -1174,10 +1211,10 @@ class HeadContractFn(torch.autograd.Function):
         dy = _as_dtype_contig(dy, xb.dtype)
         dxb = dw = None
         if ctx.needs_input_grad[0]:
-            w_t = k_transpose(w_c, C)                                # [Cin, C]
+            w_t = ctx.w_t if ctx.w_t is not None else k_transpose(w_c, C)   # [Cin, C]
             dxb = torch.empty((Bq, heads, Cin), dtype=xb.dtype, device=xb.device)
-            k_gemm_batched(dy, w_t, dxb, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=C, ldc=heads * Cin, a_bs=hd, b_bs=hd,
-                           c_bs=Cin)
+            k_gemm_batched(dy, w_t, dxb, batch=heads, M=Bq, N=Cin, K=hd, lda=C, ldb=w_t.stride(0), ldc=heads * Cin, a_bs=hd,
+                           b_bs=hd, c_bs=Cin)
         if ctx.needs_input_grad[1]:
             dw = _per_head_wgrad(dy, xb, heads, hd, Cin)
             if ctx.w_dtype != torch.float32:

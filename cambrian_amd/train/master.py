@@ -18,9 +18,11 @@ from typing import Iterable, List, Optional
 import torch
 
 
-class MasterAdamW:
+class MasterAdamW(torch.optim.AdamW):
     """AdamW (decoupled weight decay, torch.optim.AdamW's update rule) over fp32 masters of low-precision parameters;
-    parameters already in ``master_dtype`` are stepped in place."""
+    parameters already in ``master_dtype`` are stepped in place.  It IS a ``torch.optim.AdamW`` over (masters + full-precision
+    parameters) — ``param_groups`` / ``state`` are the real ones, so ``torch.optim.lr_scheduler.*`` and HF ``get_scheduler``
+    (the reference's cosine schedule with warm-up) attach to it like to any optimizer."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, master_dtype: torch.dtype = torch.float32):
@@ -30,25 +32,27 @@ class MasterAdamW:
         self.masters = [torch.nn.Parameter(p.detach().to(master_dtype), requires_grad=True) for p in self.low]
         every = self.masters + self.full
         fused = bool(every) and all(t.is_cuda for t in every)
-        self.inner = torch.optim.AdamW(every, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                                       **({"fused": True} if fused else {}))
+        super().__init__(every, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **({"fused": True} if fused else {}))
 
     @property
-    def param_groups(self):
-        return self.inner.param_groups
+    def inner(self):   # (round-5 name of the wrapped optimizer)
+        return self
 
-    def step(self) -> None:
+    def step(self, closure=None):
         live = [(m, p) for m, p in zip(self.masters, self.low) if p.grad is not None]
         if live:
+            # one multi-tensor up-cast of the gradients (transient: 4 B per low-precision parameter, returned to the caching
+            # allocator after the step — the same peak as persistent buffers would pin for good)
             g32 = [torch.empty_like(m) for m, _ in live]
-            torch._foreach_copy_(g32, [p.grad for _, p in live])      # one multi-tensor up-cast of the gradients
+            torch._foreach_copy_(g32, [p.grad for _, p in live])
             for (m, _), g in zip(live, g32):
                 m.grad = g
-        self.inner.step()
+        out = super().step(closure)
         if live:
             torch._foreach_copy_([p.data for _, p in live], [m.data for m, _ in live])   # compute copy = the master's cast
             for m, _ in live:
                 m.grad = None
+        return out
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.low + self.full:
@@ -65,11 +69,26 @@ class MasterAdamW:
                 + sum(p.numel() * p.element_size() * 2 for p in self.full))
 
     def state_dict(self) -> dict:
-        return {"inner": self.inner.state_dict(), "masters": [m.detach().clone() for m in self.masters]}
+        sd = super().state_dict()
+        sd["masters"] = [m.detach().clone() for m in self.masters]
+        return sd
 
     def load_state_dict(self, sd: dict) -> None:
-        self.inner.load_state_dict(sd["inner"])
+        sd = dict(sd)
+        masters = sd.pop("masters")
+        if "inner" in sd:   # a round-5 checkpoint
+            sd = sd["inner"]
+        if len(masters) != len(self.masters) or any(t.shape != m.shape for t, m in zip(masters, self.masters)):
+            raise ValueError(f"MasterAdamW: the checkpoint holds {len(masters)} masters, this optimizer {len(self.masters)} "
+                             "(or their shapes differ): other parameters, or another order")
+        super().load_state_dict(sd)
         with torch.no_grad():
-            for m, t, p in zip(self.masters, sd["masters"], self.low):
+            for m, t, p in zip(self.masters, masters, self.low):
                 m.copy_(t)
                 p.copy_(m)
+
+    def resync_masters(self) -> None:
+        """Masters := the parameters as they are now (weights loaded into the module after the optimizer was built)."""
+        with torch.no_grad():
+            for m, p in zip(self.masters, self.low):
+                m.copy_(p)

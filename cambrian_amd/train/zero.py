@@ -89,6 +89,7 @@ class Zero2AdamW:
         self._where = {}
         self._handles = []
         self._sync = True  # False inside no_sync(): accumulate only, no collective
+        self._masters_checked = False   # first step(): masters still equal the parameters? (resync_masters / load_state_dict)
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
@@ -132,6 +133,8 @@ class Zero2AdamW:
 
     # ---- optimizer side ------------------------------------------------------------------------------------------
     def step(self) -> None:
+        if not self._masters_checked:
+            self._check_masters()
         gathers = []
         for b, s in zip(self.buckets, self._shards):
             if b.work is None and (b.pending != 0 or self.world == 1):
@@ -177,6 +180,56 @@ class Zero2AdamW:
                 p.grad = None
         for s_ in self._shards:
             s_.grad = None
+
+    # ---- masters and checkpoints ---------------------------------------------------------------------------
+    # The fp32 master of the owned shard is a SNAPSHOT taken when the optimizer is built; step() overwrites the compute-dtype
+    # shard with the master's cast.  Weights loaded into the module afterwards (a checkpoint, resize_token_embeddings, a
+    # re-initialisation) must therefore be handed to the masters — ``resync_masters()`` — or they are reverted by the first
+    # step.  Build the optimizer AFTER loading weights where possible; the first step() checks the two agree and raises.
+    def resync_masters(self) -> None:
+        """Masters := the parameters as they are now (after loading weights into a module whose optimizer already exists)."""
+        for b in self.buckets:
+            if b.master_shard is not None:
+                b.master_shard.copy_(b.param_shard)
+        self._masters_checked = True
+
+    def _check_masters(self) -> None:
+        for i, b in enumerate(self.buckets):
+            if b.master_shard is not None and not torch.equal(b.master_shard.to(b.param_shard.dtype), b.param_shard):
+                raise RuntimeError(f"Zero2AdamW: bucket {i}'s parameters changed after the optimizer was built (weights loaded "
+                                   "into the module afterwards?); call resync_masters() or they would be reverted by this step")
+        self._masters_checked = True
+
+    def state_dict(self) -> dict:
+        """This rank's state: AdamW moments of the owned shards, the fp32 masters, and the sharding it belongs to."""
+        return {"inner": self.inner.state_dict(), "world": self.world, "rank": self.rank,
+                "shard_len": [b.shard_len for b in self.buckets],
+                "masters": [None if b.master_shard is None else b.master_shard.detach().clone() for b in self.buckets],
+                "param_shards": [b.param_shard.detach().clone() for b in self.buckets]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Restores what ``state_dict()`` of the SAME sharding (world, rank, bucket layout) saved; the module's parameters are
+        rewritten from the masters (all ranks must call it)."""
+        if sd["world"] != self.world or sd["rank"] != self.rank:
+            raise ValueError(f"Zero2AdamW state of rank {sd['rank']} / world {sd['world']} loaded on rank {self.rank} / world {self.world}")
+        if list(sd["shard_len"]) != [b.shard_len for b in self.buckets]:
+            raise ValueError("Zero2AdamW: the checkpoint's bucket layout differs (other parameters, bucket_mb or world size)")
+        for b, m, ps in zip(self.buckets, sd["masters"], sd["param_shards"]):
+            if (m is None) != (b.master_shard is None):
+                raise ValueError("Zero2AdamW: checkpoint and optimizer disagree on which buckets carry fp32 masters")
+            if m is not None:
+                if m.shape != b.master_shard.shape:
+                    raise ValueError("Zero2AdamW: master shard shape mismatch")
+                b.master_shard.copy_(m)
+                b.param_shard.copy_(b.master_shard)
+            else:
+                b.param_shard.copy_(ps)
+        self.inner.load_state_dict(sd["inner"])
+        gathers = [dist.all_gather_into_tensor(b.flat_param, b.param_shard, group=self.group, async_op=True)
+                   for b in self.buckets] if self.world > 1 else []
+        for w in gathers:
+            w.wait()
+        self._masters_checked = True
 
     def state_bytes(self) -> int:
         """optimizer-state bytes held by THIS rank: two moments per owned element in the stepping dtype (+ the master copy)."""

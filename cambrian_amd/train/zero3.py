@@ -264,12 +264,49 @@ class Zero3Unit:
         if Zero3Unit._bw_prev is self:
             Zero3Unit._bw_prev = None
 
-    def full_state(self) -> List[torch.Tensor]:
-        """Every parameter, materialised (for checkpointing / tests)."""
+    def full_state(self, master: bool = False) -> List[torch.Tensor]:
+        """Every parameter, materialised (for checkpointing / tests).  ``master=True``: in the precision the optimizer steps
+        on (the fp32 masters all-gathered as they are — what a checkpoint must keep); else the compute-dtype cast."""
+        if master and self.master:
+            flat = torch.empty(self.padded, device=self.shard.device, dtype=self.shard.dtype)
+            if self.world > 1:
+                dist.all_gather_into_tensor(flat, self.shard.data, group=self.group)
+            else:
+                flat.copy_(self.shard.data)
+            out, off = [], 0
+            for p in self.params:
+                out.append(flat[off:off + p.numel()].view(p.shape).clone())
+                off += p.numel()
+            return out
         self.gather()
         out = [p.detach().clone() for p in self.params]
         self.release()
         return out
+
+    def load_full_state(self, tensors: List[torch.Tensor]) -> None:
+        """Weights for a unit that already exists (its parameters are released views: ``module.load_state_dict`` cannot reach
+        them): every rank passes the full tensors in ``self.params`` order and keeps its own slice, in the shard's precision."""
+        if len(tensors) != len(self.params) or any(t.shape != p.shape for t, p in zip(tensors, self.params)):
+            raise ValueError("Zero3Unit.load_full_state: one tensor per parameter, in the module's parameter order and shapes")
+        flat = torch.zeros(self.padded, device=self.shard.device, dtype=self.shard.dtype)
+        off = 0
+        for t in tensors:
+            flat[off:off + t.numel()].copy_(t.reshape(-1))
+            off += t.numel()
+        lo = self.rank * self.shard_len
+        self.shard.data.copy_(flat[lo:lo + self.shard_len])
+
+    def state_dict(self) -> dict:
+        """This rank's shard in the stepping precision (the fp32 master when there is one) and the sharding it belongs to."""
+        return {"shard": self.shard.detach().clone(), "master": self.master, "world": self.world, "rank": self.rank,
+                "shard_len": self.shard_len}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if (sd["world"], sd["rank"], sd["shard_len"], sd["master"]) != (self.world, self.rank, self.shard_len, self.master):
+            raise ValueError("Zero3Unit: the checkpoint belongs to another sharding (world, rank, unit size or master dtype)")
+        if sd["shard"].shape != self.shard.shape:
+            raise ValueError("Zero3Unit: shard shape mismatch")
+        self.shard.data.copy_(sd["shard"])
 
 
 def zero3_wrap(modules: Iterable[nn.Module], process_group: Optional[dist.ProcessGroup] = None,

@@ -85,11 +85,12 @@ int cmb_abi_version(void);
  *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
  *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
  *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 7 (one wave per SIMD) or 4 (two)
- *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask: 1 = forward, 2 = dQ, 8 = dK/dV on LDS-DMA operand tiles with transposing
- *                       reads (flash2.hip; 8 needs 2); 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 16 = that
- *                       kernel reading its Q^T / dO^T fragments with transposing reads from swizzled row-major images (no transposed
- *                       copies); 0 = the round-4 kernels.  Default 23 (the LDS-DMA dK/dV kernel measured slower than 4 | 16:
- *                       profiles/r05_lab.md).  dQ / dK / dV are bit-identical across variants, the forward to fp32 rounding */
+ *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask: 1 = forward, 2 = dQ on LDS-DMA operand tiles with transposing reads
+ *                       (flash2.hip); 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 16 = that kernel reading its
+ *                       Q^T / dO^T fragments with transposing reads from swizzled row-major images (no transposed copies); 0 = the
+ *                       round-4 kernels.  Default 23.  (Bit 8 selected a dK/dV kernel on LDS-DMA tiles that measured slower —
+ *                       profiles/r05_lab.md — and was removed in round 6: values with it are rejected.)  dQ / dK / dV are
+ *                       bit-identical across variants, the forward to fp32 rounding (tests/test_flash_bwd_gpu.py) */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
                    CMB_KNOB_FLASH = 5, CMB_KNOB_COUNT = 8 };
 #define CMB_KNOB_DEFAULTS 1, 1, 2, 0, 4, 23, 0, 0

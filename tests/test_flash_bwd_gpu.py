@@ -202,3 +202,58 @@ def test_vit_attention_bidirectional_padded(dev, B, N, H, hd):
         assert a.shape == b.shape
         err = ((a.float() - b).abs().max() / b.abs().max()).item()
         assert err < 3e-2, f"{name}: rel err {err}"
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_every_shipped_flash_variant(dev, masked):
+    """CMB_KNOB_FLASH: every variant the library ships — 0 (round-4 kernels), 4 (four-phase dK/dV body), 7
+    (+ forward and dQ on LDS-DMA tiles), 23 (default: + transposing reads in dK/dV), and the single bits 1, 2, 16, 20 — against
+    fp32 autograd of the plain formula, with dQ / dK / dV BIT-IDENTICAL across variants and the forward equal to fp32 rounding,
+    as include/cambrian_amd.h claims; causal and causal + key-padding (the collator's mask)."""
+    from cambrian_amd import lib as L
+    from cambrian_amd import ops
+    B, S, H, HKV, D = 2, 1024, 8, 2, 128
+    g_ = torch.Generator().manual_seed(11)
+    qs = torch.randn(B, S, H, D, generator=g_).to(torch.bfloat16).to(dev)
+    ks = torch.randn(B, S, HKV, D, generator=g_).to(torch.bfloat16).to(dev)
+    vs = torch.randn(B, S, HKV, D, generator=g_).to(torch.bfloat16).to(dev)
+    w = torch.randn(B, H, S, D, generator=g_).to(dev)
+    key_valid = _collator_key_mask(B, S, [(336, 200), (224, 336)]).to(dev) if masked else None
+    # fp32 reference
+    qr, kr, vr = (t.transpose(1, 2).detach().float().requires_grad_() for t in (qs, ks, vs))
+    s = qr @ kr.repeat_interleave(H // HKV, 1).transpose(-1, -2) / math.sqrt(D)
+    allow = torch.ones(S, S, dtype=torch.bool, device=dev).tril_()[None, None]
+    if masked:
+        allow = allow & (key_valid[:, None, None, :] | torch.eye(S, dtype=torch.bool, device=dev)[None, None])
+    ref = torch.softmax(s.masked_fill(~allow, float("-inf")), -1) @ vr.repeat_interleave(H // HKV, 1)
+    (ref * w).sum().backward()
+    results = {}
+    default = L.load().cmb_knob_get(L.KNOB_FLASH)
+    try:
+        for knob in (0, 4, 7, 23, 1, 2, 16, 20):
+            L.knob_set(L.KNOB_FLASH, knob)
+            q, k, v = (t.transpose(1, 2).detach().requires_grad_() for t in (qs, ks, vs))
+            out = ops.causal_attention(q, k, v, key_valid=key_valid)
+            (out.float() * w).sum().backward()
+            results[knob] = (out.detach(), q.grad, k.grad, v.grad)
+            assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < 2e-2, f"knob {knob}: forward"
+            for name, a, b in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+                err = ((a.float() - b).abs().max() / b.abs().max()).item()
+                assert err < 3e-2, f"knob {knob} {name}: rel err {err}"
+        with pytest.raises(L.CambrianAmdError):
+            L.knob_set(L.KNOB_FLASH, 8 | 2)      # the removed dK/dV variant is rejected, not silently mapped
+    finally:
+        L.knob_set(L.KNOB_FLASH, default)
+    base = results[0]
+    for knob, r in results.items():
+        fwd_new = bool(knob & 1)
+        if not fwd_new:
+            assert torch.equal(r[0], base[0]), f"knob {knob}: forward differs from the round-4 kernel"
+        else:   # two partial row sums: one bf16 ulp at most on an output
+            assert (r[0].float() - base[0].float()).abs().max().item() <= 2.0 ** -7 * base[0].float().abs().max().item()
+    # the backward kernels are bit-identical to each other GIVEN the same forward outputs (o, lse): compare within each forward
+    for group in ((0, 4, 2, 16, 20), (7, 23, 1)):
+        a = results[group[0]]
+        for knob in group[1:]:
+            for i, name in ((1, "dq"), (2, "dk"), (3, "dv")):
+                assert torch.equal(results[knob][i], a[i]), f"knob {knob}: {name} differs from knob {group[0]}"

@@ -127,6 +127,43 @@ def _worker(rank, world, port, q, kind):
             m2(_grads(world, step, rank)).backward()
             o2.step()
         ok = ok and any(not torch.equal(p.detach(), w.to(torch.bfloat16)) for p, w in zip(m2.ps, want))
+        # (a) checkpoint / resume — state_dict() carries the fp32 masters and the moments: a run resumed after one
+        # step lands where the uninterrupted run does
+        m3 = _Dot(_init_params(torch.bfloat16))
+        o3 = Zero2AdamW(list(m3.parameters()), lr=LR, weight_decay=WD, bucket_mb=0.004)
+        m3(_grads(world, 0, rank)).backward()
+        o3.step()
+        sd = o3.state_dict()
+        m4 = _Dot(_init_params(torch.bfloat16))
+        o4 = Zero2AdamW(list(m4.parameters()), lr=LR, weight_decay=WD, bucket_mb=0.004)
+        o4.load_state_dict(sd)
+        for step in range(1, STEPS):
+            m4(_grads(world, step, rank)).backward()
+            o4.step()
+        for p, w in zip(m4.ps, want):
+            ok = ok and torch.equal(p.detach(), w.to(torch.bfloat16))
+        bad = dict(sd, rank=1 - rank)
+        try:
+            o4.load_state_dict(bad)
+            ok = False
+        except ValueError:
+            pass
+        # (b) weights loaded AFTER the optimizer was built: the first step refuses to revert them; resync_masters() adopts them
+        m5 = _Dot(_init_params(torch.bfloat16))
+        o5 = Zero2AdamW(list(m5.parameters()), lr=LR, weight_decay=WD, bucket_mb=0.004)
+        with torch.no_grad():
+            for p in m5.ps:
+                p.mul_(2.0)
+        m5(_grads(world, 0, rank)).backward()
+        try:
+            o5.step()
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "resync_masters" in str(e)
+        o5.resync_masters()
+        o5.step()
+        ok = ok and all(torch.allclose(b.master_shard, b.param_shard.float(), atol=2e-2, rtol=1e-2) for b in o5.buckets)
+        ok = ok and all((p.detach().float().abs() > 0.5 * (2.0 * w0.float().abs()) - 1e-2).all() for p, w0 in zip(m5.ps, _init_params(torch.float32)))
     else:
         from cambrian_amd.train.zero3 import zero3_parameters, zero3_wrap
         m = _Dot(_init_params(torch.bfloat16))
@@ -144,6 +181,25 @@ def _worker(rank, world, port, q, kind):
         flat_w = torch.cat([flat_w, torch.zeros(u.padded - flat_w.numel())])
         lo = rank * u.shard_len
         ok = ok and torch.allclose(u.shard.detach(), flat_w[lo:lo + u.shard_len], atol=1e-6, rtol=0)
+        # the fp32 masters are what a checkpoint keeps — full_state(master=True) is the fp32 trajectory, a new unit
+        # takes it (load_full_state) or this rank's shard (state_dict / load_state_dict) without losing precision
+        for a, w in zip(u.full_state(master=True), want):
+            ok = ok and a.dtype == torch.float32 and torch.allclose(a, w, atol=1e-6, rtol=0)
+        m6 = _Dot(_init_params(torch.bfloat16))
+        (u6,) = zero3_wrap([m6])
+        u6.load_full_state(u.full_state(master=True))
+        ok = ok and torch.equal(u6.shard.detach(), u.shard.detach())
+        m7 = _Dot(_init_params(torch.bfloat16))
+        (u7,) = zero3_wrap([m7])
+        u7.load_state_dict(u.state_dict())
+        ok = ok and torch.equal(u7.shard.detach(), u.shard.detach())
+        for a, b_ in zip(u7.full_state(), u.full_state()):
+            ok = ok and torch.equal(a, b_)
+        try:
+            u7.load_state_dict(dict(u.state_dict(), rank=1 - rank))
+            ok = False
+        except ValueError:
+            pass
         # a frozen unit carries no master
         f = _Dot(_init_params(torch.bfloat16))
         for p in f.parameters():

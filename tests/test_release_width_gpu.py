@@ -182,5 +182,11 @@ def test_release_width_end_to_end(dev, monkeypatch, name, dt, tol_logits, tol_gr
             assert ours[k] <= 1.5 * ref[k], (k, ours[k], ref[k])
         # loss (11.18): the reference's own bf16 run is off by 1.5e-4; this path by 4.5e-4 with the round-4 attention forward and
         # 5.3e-4 with the round-5 one (its row sums are accumulated in two partial sums: one bf16 ulp on some attention outputs) —
-        # 4-5e-5 relative either way.  Bound: 1e-4 relative.
-        assert dloss <= 1e-4 * 11.18, dloss
+        # 4-5e-5 relative either way.  The round-4 forward (CMB_KNOB_FLASH bit 0 clear) is held to the bound it was written
+        # against — twice the reference's own bf16 error, at least 5e-4; the round-5 forward to 6.5e-4 = its observed 5.3e-4
+        # + 20 %, i.e. 5.8e-5 relative: an explicit figure, not a bound widened until it fit.
+        from cambrian_amd import lib as _L
+        if _L.knob_get(_L.KNOB_FLASH) & 1:
+            assert dloss <= 6.5e-4, dloss
+        else:
+            assert dloss <= max(2.0 * twin["loss_abs_err"], 5e-4), dloss
