@@ -395,7 +395,11 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   p.batch = d->batch > 1 ? d->batch : 1;
   p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
   p.slab_rows = p.M;
+  p.row_mean = d->row_mean; p.row_rstd = d->row_rstd; p.col_sum = d->col_sum;
   int splits = d->split_k > 1 ? d->split_k : 1;
+  if (d->row_mean && (!d->row_rstd || !d->col_sum || !d->bias || d->alpha != 1.0f || splits > 1 || p.batch > 1 || sizeof(T) != 2 ||
+                      d->pre_out))
+    return CMB_ERR_BAD_ARG;   // the folded-LayerNorm epilogue: bf16 operands, bias (b'), one launch over the whole K
   if (d->act == CMB_ACT_SWIGLU_PAIRS &&
       (splits > 1 || d->colscale || d->residual || d->pre_out || d->out_dtype != d->dtype || d->N % 16 != 0 || p.batch > 1 ||
        sizeof(T) == 1))
@@ -442,6 +446,7 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
       tail.C += row_off(p.c_map, (uint32_t)m1) * (p.out_f32 ? 4 : 2);
       if (p.R) tail.R += row_off(p.r_map, (uint32_t)m1) * 2;
       if (p.P) tail.P += row_off(p.p_map, (uint32_t)m1) * 2;
+      if (p.row_mean) tail.row_mean += m1, tail.row_rstd += m1;
       const int kern = choose_bf16_kernel(head, 1, 256, &sched);   // (256: the 256-tile branch of the cost model, no policy)
       g_last_kernel = kern;
       if (kern == 128) {
@@ -502,6 +507,8 @@ int gemm_tn_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   p.batch = d->batch > 1 ? d->batch : 1;
   p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
   p.slab_rows = p.M;
+  p.row_mean = p.row_rstd = p.col_sum = nullptr;
+  if (d->row_mean) return CMB_ERR_BAD_ARG;
   int splits = d->split_k > 1 ? d->split_k : 1;
   if (p.batch > 1) {
     if ((p.a_bs * 2) % 16 || (p.b_bs * 2) % 16 || (p.c_bs * 2) % 16) return CMB_ERR_ALIGNMENT;

@@ -27,6 +27,9 @@ struct GemmParams {
   int batch;                 // > 1: blockIdx.z walks independent problems of the same shape (128 x 128 kernel only)
   int64_t a_bs, b_bs, c_bs;  // element strides of A / B / C between consecutive problems of a batch
   int slab_rows;             // rows of one split-K slab (= M; batch * M for cmb_gemm_tn's batched split-K)
+  const float* row_mean;     // LayerNorm folded into this linear (cmb_gemm_desc.row_mean): v = rstd[m] (acc - mean[m] colsum[n]) + bias[n]
+  const float* row_rstd;
+  const float* col_sum;
 };
 
 // storage tag of an OCP e4m3fn operand byte (gfx950 native fp8)
@@ -103,7 +106,14 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmParams& p, int kz, int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= sa * sb[e];
   }
-  if (p.bias) {
+  if (p.row_mean) {   // folded LayerNorm: the same two fused multiply-adds per element as gemm_p5_epilogue.inc
+    float bb[8], cs[8];
+    load8f(p.bias + gn, bb);
+    load8f(p.col_sum + gn, cs);
+    const float nm = -p.row_mean[gm], rs = p.row_rstd[gm];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(rs, fmaf(nm, cs[e], v[e]), bb[e]);
+  } else if (p.bias) {
     float bb[8];
     load8f(p.bias + gn, bb);
 #pragma unroll

@@ -217,6 +217,68 @@ __global__ void __launch_bounds__(256) layernorm_fwd_lds_kernel(
   }
 }
 
+// Row statistics only (round 6): mean / rstd of every row, the arithmetic of layernorm_fwd_lds_kernel operation for operation
+// (two passes over the row in registers, next row prefetched), no normalised output — the LayerNorm itself is applied by the
+// epilogue of the linear that follows (cmb_gemm_desc.row_mean): half of a LayerNorm's HBM traffic.
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) row_stats_kernel(const T* __restrict__ x, int64_t rows, int D, int64_t ldx, float eps,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int nvec = D >> 3;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  Raw8<T> cur[NCH], nxt[NCH];
+  int64_t row = wave_global;
+  if (row < rows) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) cur[c].load(x + row * ldx + vi * 8);
+    }
+  }
+  for (; row < rows; row += nwaves) {
+    const int64_t nrow = row + nwaves;
+    if (nrow < rows) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int vi = lane + c * 64;
+        if (vi < nvec) nxt[c].load(x + nrow * ldx + vi * 8);
+      }
+    }
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+        cur[c].get(v[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[c][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int vi = lane + c * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[c][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cur[c] = nxt[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm backward.  Rows are enumerated window-major so that all rows a block touches share one
 // position-table row: blockIdx.y = pos (0..grid_r^2-1), and "window" w enumerates
@@ -853,6 +915,27 @@ extern "C" int cmb_layernorm_fwd(int dtype, const void* x, int64_t rows, int64_t
   if (dtype == CMB_F32)
     return ln_fwd<float>(x, rows, D, ldx, add, side, grid_r, gamma, beta, eps, y, ldy, mean, rstd, s);
   return CMB_ERR_BAD_ARG;
+}
+
+extern "C" int cmb_row_stats(int dtype, const void* x, int64_t rows, int64_t D, int64_t ldx, float eps, float* mean, float* rstd,
+                             void* stream) {
+  if (!x || !mean || !rstd || rows < 0 || D <= 0 || (D & 7) || D > 4096 || (ldx & 7)) return CMB_ERR_BAD_ARG;
+  if (rows == 0) return CMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = nch_for(D);
+  int64_t blocks = (rows + 15) / 16;   // ~4 rows per wave (as layernorm_fwd_lds_kernel's launch)
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == CMB_BF16) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((row_stats_kernel<bf16_t, NCH>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x,
+                                         rows, (int)D, ldx, eps, mean, rstd));
+  } else if (dtype == CMB_F32) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((row_stats_kernel<float, NCH>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x,
+                                         rows, (int)D, ldx, eps, mean, rstd));
+  } else {
+    return CMB_ERR_BAD_ARG;
+  }
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
 }
 
 // dx dtype: same as `dtype` when dx_accumulate == 0; fp32 when dx_accumulate != 0 (the cross-layer

@@ -54,6 +54,7 @@ class GemmDesc(C.Structure):
         ("tile_hint", C.c_int32),
         ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
         ("batch", C.c_int32), ("a_batch_stride", C.c_int64), ("b_batch_stride", C.c_int64), ("c_batch_stride", C.c_int64),
+        ("row_mean", C.c_void_p), ("row_rstd", C.c_void_p), ("col_sum", C.c_void_p),
     ]
 
 
@@ -156,6 +157,7 @@ SIGNATURES = {
     "cmb_weight_prep_tiles": (_i64, [_i64, _i64]),
     "cmb_weight_prep_one": (C.c_int, [C.POINTER(PrepJob), _p]),
     "cmb_weight_prep": (C.c_int, [_p, _i32, _i64, _p]),
+    "cmb_row_stats": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _f, _p, _p, _p]),
     "cmb_layernorm_bwd_multi": (C.c_int, [C.POINTER(LnMultiDesc), _p]),
     "cmb_layernorm_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _p, _i64, _p, _p, _p]),
     "cmb_layernorm_bwd": (C.c_int, [C.c_int, _p, _i64, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _i64,

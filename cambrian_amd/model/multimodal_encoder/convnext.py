@@ -86,6 +86,7 @@ class ConvNeXtTrunk(nn.Module):
         def buf(name, t, dtype):
             self.register_buffer(name, t.to(dtype).contiguous().to(device), persistent=False)
 
+        self._ln_fused = fuse = bool(vit_ops.LN_FUSE and dt == torch.bfloat16)   # block ln -> fc1 folded (vit_ops.fold_ln_into_linear)
         c0 = cfg.dims[0]
         K = cfg.num_channels * 16
         self.kpad = (K + ks - 1) // ks * ks
@@ -111,8 +112,15 @@ class ConvNeXtTrunk(nn.Module):
                 buf(n + "dw_b", p[pre + "dw.bias"], torch.float32)
                 buf(n + "ln_w", p[pre + "ln.weight"], torch.float32)
                 buf(n + "ln_b", p[pre + "ln.bias"], torch.float32)
-                buf(n + "fc1_w", p[pre + "fc1.weight"], dt)
-                buf(n + "fc1_b", p[pre + "fc1.bias"], torch.float32)
+                if fuse:
+                    w2, cs, b2 = vit_ops.fold_ln_into_linear(p[pre + "fc1.weight"], p[pre + "fc1.bias"], p[pre + "ln.weight"],
+                                                             p[pre + "ln.bias"], dt)
+                    buf(n + "fc1_w", w2, dt)
+                    buf(n + "fc1_b", b2, torch.float32)
+                    buf(n + "fc1_cs", cs, torch.float32)
+                else:
+                    buf(n + "fc1_w", p[pre + "fc1.weight"], dt)
+                    buf(n + "fc1_b", p[pre + "fc1.bias"], torch.float32)
                 buf(n + "fc2_w", p[pre + "fc2.weight"], dt)
                 buf(n + "fc2_b", p[pre + "fc2.bias"], torch.float32)
                 if cfg.layer_scale:
@@ -144,8 +152,12 @@ class ConvNeXtTrunk(nn.Module):
             for b in range(depth):
                 g = lambda n: getattr(self, f"s{s}_b{b}_{n}")  # noqa: E731
                 y = vit_ops.k_dwconv7x7(x.view(B, H, H, c), g("dw_w"), g("dw_b")).view(-1, c)
-                yn, _, _ = ops.k_layernorm_fwd(y, g("ln_w"), g("ln_b"), cfg.ln_eps, want_stats=False)
-                h = ops.k_gemm(yn, g("fc1_w"), bias=g("fc1_b"), act=L.ACT_GELU_ERF)
+                if self._ln_fused:   # row statistics + the LayerNorm inside fc1's epilogue: no normalised copy of the map
+                    h = ops.k_gemm(y, g("fc1_w"), bias=g("fc1_b"), act=L.ACT_GELU_ERF, row_stats=ops.k_row_stats(y, cfg.ln_eps),
+                                   col_sum=g("fc1_cs"))
+                else:
+                    yn, _, _ = ops.k_layernorm_fwd(y, g("ln_w"), g("ln_b"), cfg.ln_eps, want_stats=False)
+                    h = ops.k_gemm(yn, g("fc1_w"), bias=g("fc1_b"), act=L.ACT_GELU_ERF)
                 x = ops.k_gemm(h, g("fc2_w"), bias=g("fc2_b"), colscale=g("gamma") if cfg.layer_scale else None,
                                residual=x)
             outs.append(x.view(B, H, H, c))

@@ -160,6 +160,8 @@ class ViTTrunk(nn.Module):
                 buf(name + "_b", p[f"{name}.bias"], torch.float32)
         nl = cfg.run_layers if cfg.run_layers is not None else cfg.num_layers
         self.nl = nl
+        # ln1 -> qkv and ln2 -> fc1 with the LayerNorm folded into the GEMM (vit_ops.fold_ln_into_linear): bf16 towers
+        self._ln_fused = fuse = bool(vit_ops.LN_FUSE and dt == torch.bfloat16)
         for l in range(nl):
             pre = f"layers.{l}."
             for n in ("ln1", "ln2"):
@@ -175,8 +177,15 @@ class ViTTrunk(nn.Module):
                 wp[:, :hd], bp[:, :hd] = w, b
                 ws.append(wp.reshape(H * hdp, D))
                 bs.append(bp.reshape(H * hdp))
-            buf(f"l{l}_qkv_w", torch.cat(ws, 0), dt)
-            buf(f"l{l}_qkv_b", torch.cat(bs, 0), torch.float32)
+            if fuse:
+                w2, cs, b2 = vit_ops.fold_ln_into_linear(torch.cat(ws, 0), torch.cat(bs, 0), p[pre + "ln1.weight"],
+                                                         p[pre + "ln1.bias"], dt)
+                buf(f"l{l}_qkv_w", w2, dt)
+                buf(f"l{l}_qkv_b", b2, torch.float32)
+                buf(f"l{l}_qkv_cs", cs, torch.float32)
+            else:
+                buf(f"l{l}_qkv_w", torch.cat(ws, 0), dt)
+                buf(f"l{l}_qkv_b", torch.cat(bs, 0), torch.float32)
             pw = p[pre + "proj.weight"].float().view(D, H, hd)
             pwp = torch.zeros(D, H, hdp, device=pw.device)
             pwp[:, :, :hd] = pw
@@ -194,8 +203,14 @@ class ViTTrunk(nn.Module):
             else:
                 w1p = _pad_rows(p[pre + "fc1.weight"].float(), Fp)
                 b1p = _pad_rows(p[pre + "fc1.bias"].float()[:, None], Fp)[:, 0]
-            buf(f"l{l}_fc1_w", w1p, dt)
-            buf(f"l{l}_fc1_b", b1p, torch.float32)
+            if fuse:
+                w2, cs, b2 = vit_ops.fold_ln_into_linear(w1p, b1p, p[pre + "ln2.weight"], p[pre + "ln2.bias"], dt)
+                buf(f"l{l}_fc1_w", w2, dt)
+                buf(f"l{l}_fc1_b", b2, torch.float32)
+                buf(f"l{l}_fc1_cs", cs, torch.float32)
+            else:
+                buf(f"l{l}_fc1_w", w1p, dt)
+                buf(f"l{l}_fc1_b", b1p, torch.float32)
             buf(f"l{l}_fc2_w", _pad_cols(p[pre + "fc2.weight"].float(), Fp), dt)
             buf(f"l{l}_fc2_b", p[pre + "fc2.bias"], torch.float32)
             if cfg.layerscale:
@@ -236,12 +251,19 @@ class ViTTrunk(nn.Module):
         scale = 1.0 / math.sqrt(cfg.head_dim)
         for l in range(self.nl):
             g = lambda n: self._b(f"l{l}_{n}")  # noqa: E731
-            h, _, _ = ops.k_layernorm_fwd(x, g("ln1_w"), g("ln1_b"), cfg.ln_eps, want_stats=False)
-            qkv = ops.k_gemm(h, g("qkv_w"), bias=g("qkv_b"))
+            if self._ln_fused:   # row statistics + the LayerNorm inside the GEMM's epilogue: no normalised copy
+                qkv = ops.k_gemm(x, g("qkv_w"), bias=g("qkv_b"), row_stats=ops.k_row_stats(x, cfg.ln_eps), col_sum=g("qkv_cs"))
+            else:
+                h, _, _ = ops.k_layernorm_fwd(x, g("ln1_w"), g("ln1_b"), cfg.ln_eps, want_stats=False)
+                qkv = ops.k_gemm(h, g("qkv_w"), bias=g("qkv_b"))
             a = vit_ops.k_vit_attn(qkv, B, N, cfg.num_heads, cfg.head_dim_pad, scale)
             x = ops.k_gemm(a, g("proj_w"), bias=g("proj_b"), colscale=g("ls1") if cfg.layerscale else None, residual=x)
-            h, _, _ = ops.k_layernorm_fwd(x, g("ln2_w"), g("ln2_b"), cfg.ln_eps, want_stats=False)
-            f = ops.k_gemm(h, g("fc1_w"), bias=g("fc1_b"), act=act)      # (swiglu: [tokens, F] = silu(gate) * up already)
+            if self._ln_fused:
+                f = ops.k_gemm(x, g("fc1_w"), bias=g("fc1_b"), act=act, row_stats=ops.k_row_stats(x, cfg.ln_eps),
+                               col_sum=g("fc1_cs"))
+            else:
+                h, _, _ = ops.k_layernorm_fwd(x, g("ln2_w"), g("ln2_b"), cfg.ln_eps, want_stats=False)
+                f = ops.k_gemm(h, g("fc1_w"), bias=g("fc1_b"), act=act)  # (swiglu: [tokens, F] = silu(gate) * up already)
             x = ops.k_gemm(f, g("fc2_w"), bias=g("fc2_b"), colscale=g("ls2") if cfg.layerscale else None, residual=x)
         if cfg.final_ln:
             x, _, _ = ops.k_layernorm_fwd(x, self.final_ln_w, self.final_ln_b, cfg.ln_eps, want_stats=False)

@@ -1,11 +1,31 @@
 """Raw launchers of the vision-tower kernels (forward only: the towers are frozen)."""
 from __future__ import annotations
 
-from typing import Optional
+import os
+from typing import Optional, Tuple
 
 import torch
 
 from ... import lib as L
+
+# Round 6: the frozen towers' LayerNorm -> linear pairs (ViT ln1 -> qkv, ln2 -> fc1; ConvNeXt ln -> fc1) run as cmb_row_stats +
+# ONE GEMM on the un-normalised rows with the LayerNorm folded into its epilogue (cmb_gemm_desc.row_mean): the normalised copy
+# is never written.  bf16 towers only (the fp32 parity path keeps the separate LayerNorm); CAMBRIAN_AMD_LN_FUSE=0 packs the
+# towers the round-5 way (A/B runs).  Read when a tower packs its weights.
+LN_FUSE = os.environ.get("CAMBRIAN_AMD_LN_FUSE", "1") != "0"
+
+
+def fold_ln_into_linear(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                        dt: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """LN(x) W^T + b = rstd (x W'^T - mean colsum) + b':  W' = W diag(gamma) in ``dt`` (what the GEMM reads), colsum = the row
+    sums of W' AS STORED (so that the mean term cancels against what the matrix pipe accumulates), b' = b + W beta (fp32)."""
+    w32, g32, be32 = w.float(), gamma.float(), beta.float()
+    w2 = (w32 * g32[None, :]).to(dt)
+    col_sum = w2.float().sum(1)
+    b2 = w32 @ be32
+    if b is not None:
+        b2 = b2 + b.float()
+    return w2, col_sum, b2
 
 
 def k_vit_attn(qkv: torch.Tensor, B: int, N: int, heads: int, hd: int, scale: float, force_simple: bool = False):

@@ -54,9 +54,12 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
            residual: Optional[torch.Tensor] = None, r_map: Optional[RowMap] = None,
            out: Optional[torch.Tensor] = None, c_map: Optional[RowMap] = None, out_dtype: Optional[torch.dtype] = None,
            pre_out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
-           split_k: int = 1, tile: int = 0) -> torch.Tensor:
+           split_k: int = 1, tile: int = 0, row_stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+           col_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M,N] = epilogue(alpha * A[M,K] @ W[N,K]^T).  ``a`` is [M,K] (row stride a.stride(0)) unless an
-    explicit ``a_map``/``M`` is given, in which case ``a`` is just the base tensor."""
+    explicit ``a_map``/``M`` is given, in which case ``a`` is just the base tensor.  ``row_stats`` = (mean, rstd) [M] fp32
+    of ``k_row_stats`` + ``col_sum`` [N]: the LayerNorm in front of this linear folded into its epilogue
+    (cmb_gemm_desc.row_mean; ``w`` = W diag(gamma), ``bias`` = b + W beta, ``col_sum`` = rowsum of ``w`` as stored)."""
     L.require_gpu(a, w, bias, colscale, residual, out, pre_out)
     dt = a.dtype
     if w.dtype != dt:
@@ -110,6 +113,13 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
     d.act, d.alpha, d.beta = act, alpha, beta
     d.split_k = split_k
     d.tile_hint = tile
+    if row_stats is not None:
+        mean, rstd = row_stats
+        L.require_gpu(mean, rstd, col_sum)
+        if (col_sum is None or bias is None or any(t.dtype != torch.float32 or not t.is_contiguous() for t in (mean, rstd, col_sum))
+                or mean.numel() != M or rstd.numel() != M or col_sum.numel() != N):
+            raise L.CambrianAmdError("folded LayerNorm: mean / rstd fp32 [M], col_sum fp32 [N] and a bias are required")
+        d.row_mean, d.row_rstd, d.col_sum = mean.data_ptr(), rstd.data_ptr(), col_sum.data_ptr()
     ws = None
     if split_k > 1:
         ws = torch.empty((split_k * M * N,), dtype=torch.float32, device=a.device)
@@ -479,6 +489,18 @@ def k_layernorm_fwd(x, gamma, beta, eps, add=None, side=1, grid_r=1, want_stats=
                                     L.stream_ptr(x.device))
     L.check(rc, "cmb_layernorm_fwd")
     return y, mean, rstd
+
+
+def k_row_stats(x: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(mean, rstd) fp32 [rows] of a LayerNorm over the rows of x — no normalised output (cmb_row_stats)."""
+    L.require_gpu(x)
+    rows, D = x.shape
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rc = L.load().cmb_row_stats(L.dtype_code(x.dtype), x.data_ptr(), rows, D, x.stride(0), eps, mean.data_ptr(), rstd.data_ptr(),
+                                L.stream_ptr(x.device))
+    L.check(rc, "cmb_row_stats")
+    return mean, rstd
 
 
 def k_layernorm_bwd(dy, x, mean, rstd, gamma=None, add=None, side=1, grid_r=1, dx_acc: Optional[torch.Tensor] = None,

@@ -141,6 +141,16 @@ typedef struct cmb_gemm_desc {
                               A + z * a_batch_stride, B + z * b_batch_stride, C + z * c_batch_stride (elements; 16-byte
                               multiples).  bf16 / fp32, 128x128 tile, no bias / colscale / residual / pre_out / split-K */
   int64_t a_batch_stride, b_batch_stride, c_batch_stride;
+  /* LayerNorm folded into the linear that follows it (round 6; the frozen towers' LN -> qkv / fc1 pairs: HF / timm blocks behind
+   * clip_encoder.py:104, siglip_encoder.py:97, dino_encoder.py:159, clip_convnext_encoder.py:133-136):
+   *   LN(x) W^T + b  =  rstd[m] * ( x W'^T - mean[m] * col_sum[n] ) + b'[n],   W' = W diag(gamma) (as stored in B),
+   *   col_sum[n] = sum_k B[n,k] (of the stored, rounded values),  b' = b + W beta  (passed as `bias`)
+   * so the GEMM reads the UN-normalised rows and cmb_row_stats replaces the LayerNorm kernel (no normalised copy is written).
+   * With row_mean set the epilogue starts  v = row_rstd[m] * (acc - row_mean[m] * col_sum[n]) + bias[n]  (alpha must be 1,
+   * bias / row_rstd / col_sum non-NULL; bf16 operands; no split-K, batch, fp8 scales); act, colscale, residual follow as usual. */
+  const float* row_mean;   /* [M] fp32 or NULL */
+  const float* row_rstd;   /* [M] fp32 */
+  const float* col_sum;    /* [N] fp32 */
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);
@@ -210,6 +220,10 @@ typedef struct cmb_prep_job {
 int64_t cmb_weight_prep_tiles(int64_t rows_pad, int64_t cols);
 int cmb_weight_prep_one(const cmb_prep_job* job, void* stream);
 int cmb_weight_prep(const cmb_prep_job* jobs_device, int32_t n_jobs, int64_t total_tiles, void* stream);
+
+/* Row statistics of a LayerNorm without its output: mean[r], rstd[r] = 1 / sqrt(var + eps) of x [rows, D] (row stride ldx),
+ * the two-pass fp32 arithmetic of cmb_layernorm_fwd — the operands of cmb_gemm_desc.row_mean / row_rstd.  D % 8 == 0, D <= 4096. */
+int cmb_row_stats(int dtype, const void* x, int64_t rows, int64_t D, int64_t ldx, float eps, float* mean, float* rstd, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm   y[r,:] = (x[r,:] (+ add[pos(r),:]) - mean) * rstd (* gamma + beta)

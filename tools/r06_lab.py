@@ -154,3 +154,30 @@ if "attnone" in verbs:   # a few launches of ONE variant at ONE tower's shape: t
     for _ in range(6):
         V.k_vit_attn(qkv, B, N, heads, hdp, hd ** -0.5)
     torch.cuda.synchronize()
+
+if "lnfold" in verbs:   # LayerNorm + linear (round 5) against row statistics + the folded-LayerNorm linear, per kernel
+    from cambrian_amd.model.multimodal_encoder import vit_ops as V
+    cases = [("ConvNeXt s3 fc1", B * 4096, 6144, 1536, "gelu_erf"), ("ConvNeXt s1 fc1", B * 65536, 1536, 384, "gelu_erf"),
+             ("ConvNeXt s2 fc1", B * 16384, 3072, 768, "gelu_erf"), ("DINOv2 qkv", B * 730, 4608, 1536, "none"),
+             ("DINOv2 fc1", B * 730, 8192, 1536, "swiglu_pairs"), ("SigLIP fc1", B * 729, 4352, 1152, "gelu_erf"),
+             ("CLIP qkv", B * 577, 3072, 1024, "none")]
+    for name, M, N, K, act in cases:
+        x = rn(M, K, scale=2.0)
+        w = rn(N, K, dtype=f32, scale=K ** -0.5)
+        b, gam, bet = rn(N, dtype=f32), 1 + 0.1 * rn(K, dtype=f32), 0.1 * rn(K, dtype=f32)
+        wb = w.to(bf)
+        w2, cs, b2 = V.fold_ln_into_linear(w, b, gam, bet, bf)
+        code = L.ACT_CODES[act] if act in L.ACT_CODES else L.ACT_SWIGLU_PAIRS
+        n_out = N // 2 if act == "swiglu_pairs" else N
+        out = torch.empty(M, n_out, device=dev, dtype=bf)
+        st = ops.k_row_stats(x, 1e-6)
+        xn, _, _ = ops.k_layernorm_fwd(x, gam, bet, 1e-6, want_stats=False)
+        fns = {"ln": lambda: ops.k_layernorm_fwd(x, gam, bet, 1e-6, want_stats=False),
+               "gemm": lambda: ops.k_gemm(xn, wb, bias=b, act=code, out=out),
+               "stats": lambda: ops.k_row_stats(x, 1e-6),
+               "gemm_rs": lambda: ops.k_gemm(x, w2, bias=b2, act=code, out=out, row_stats=st, col_sum=cs),
+               "gemm_on_raw_x": lambda: ops.k_gemm(x, wb, bias=b, act=code, out=out)}
+        us = time_variants(fns)
+        emit(case="lnfold", shape=f"{name} {M}x{N}x{K} {act}", us={k: round(v, 1) for k, v in us.items()},
+             old=round(us["ln"] + us["gemm"], 1), new=round(us["stats"] + us["gemm_rs"], 1))
+        del x, xn, out
