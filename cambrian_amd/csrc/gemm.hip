@@ -437,7 +437,8 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
     int sched = 0;
     const int m1 = p.batch > 1 ? 0 : tail_split_rows(p, splits, d->tile_hint);
     if (p.batch > 1) {
-      g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, 1, s);
+      if (gemm_k64_eligible(p)) g_last_kernel = 64, rc = launch_gemm_k64_batched(p, s);   // (CMB_GEMM_K64=0: the tile kernel)
+      else g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, 1, s);
     } else if (m1) {
       GemmParams head = p, tail = p;
       head.M = m1;

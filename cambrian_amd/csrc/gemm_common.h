@@ -187,6 +187,10 @@ int launch_gemm256_bf16(GemmParams& p, int splits, int sched, hipStream_t s);
 // two LDS buffers (gemm_nt_p5_kernel)
 int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s);
 
+// gemm_k64.hip: batched problems with a 64-deep contraction and a wide N (the per-head expand products): HBM-write-bound kernel
+bool gemm_k64_eligible(const GemmParams& p);
+int launch_gemm_k64_batched(const GemmParams& p, hipStream_t s);
+
 // gemm_tn.hip: C[M,N] = At[K,M]^T Bt[K,N] (both operands row-major over the contraction rows; p.a_map.s2 = lda, p.K = rows),
 // 128 x 128 tile, transposing LDS reads
 int launch_gemm_tn_bf16(GemmParams& p, int splits, hipStream_t s);

@@ -360,7 +360,6 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
   };
 
   bool relax = false;
-  float rs_nm[4] = {0.f, 0.f, 0.f, 0.f}, rs_rs[4] = {1.f, 1.f, 1.f, 1.f};   // folded LayerNorm: (mean, rstd) of this lane's 4 rows
   constexpr uint32_t kEpiStage = 2 * kP5Buf;  // 4 x 8 KiB behind the two operand buffers
 #pragma unroll 1
   for (int c_item = first_item; c_item < n_items; c_item += stride) {
@@ -375,19 +374,6 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // folded LayerNorm (GemmParams::row_mean): this lane's row statistics for the item's epilogue, requested NOW — a whole K
-    // loop ahead of their use; they are older than every DMA piece this item issues, so the tiles' counted waits cover them
-    // (the first tile's relaxed wait, vmcnt(14 + 32), merely insists on the 8 oldest of the previous epilogue's stores too)
-    if (p.row_mean) {
-      const int e_lane0 = lane;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gm = cit.m0 + wm * 128 + i * 32 + (e_lane0 & 31);
-        const int gmc = gm < p.M ? gm : p.M - 1;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(rs_nm[i]) : "v"(p.row_mean + gmc) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(rs_rs[i]) : "v"(p.row_rstd + gmc) : "memory");
-      }
-    }
     // tile k stages tile k + 2: of this item while k + 2 < nt, else tile k + 2 - nt of the next item
     if (nt == 2) cur = src_of(next_item);
     run_tile(relax);

@@ -8,11 +8,13 @@ import torch
 
 from ... import lib as L
 
-# Round 6: the frozen towers' LayerNorm -> linear pairs (ViT ln1 -> qkv, ln2 -> fc1; ConvNeXt ln -> fc1) run as cmb_row_stats +
-# ONE GEMM on the un-normalised rows with the LayerNorm folded into its epilogue (cmb_gemm_desc.row_mean): the normalised copy
-# is never written.  bf16 towers only (the fp32 parity path keeps the separate LayerNorm); CAMBRIAN_AMD_LN_FUSE=0 packs the
-# towers the round-5 way (A/B runs).  Read when a tower packs its weights.
-LN_FUSE = os.environ.get("CAMBRIAN_AMD_LN_FUSE", "1") != "0"
+# Round 6 (measured, OFF by default): the frozen towers' LayerNorm -> linear pairs (ViT ln1 -> qkv, ln2 -> fc1; ConvNeXt ln -> fc1)
+# as cmb_row_stats + ONE GEMM on the un-normalised rows with the LayerNorm folded into its epilogue (cmb_gemm_desc.row_mean): the
+# normalised copy is never written.  Same-box A/B at 24 images: region 301.1 / 301.6 ms without, 301.0 / 301.0 with — the statistics
+# pass saves 40 % of a LayerNorm (ConvNeXt stage 3: 98.6 -> 57.2 us) and the two extra packed multiply-adds + the colsum vector cost
+# the 4-wave GEMM's one-wave-per-SIMD epilogue 3-9 % (1634 -> 1688 us): profiles/r06_lab.md.  CAMBRIAN_AMD_LN_FUSE=1 packs the
+# bf16 towers that way (tests/test_ln_fold_gpu.py keeps the path correct).  Read when a tower packs its weights.
+LN_FUSE = os.environ.get("CAMBRIAN_AMD_LN_FUSE", "0") == "1"
 
 
 def fold_ln_into_linear(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,

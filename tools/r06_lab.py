@@ -181,3 +181,15 @@ if "lnfold" in verbs:   # LayerNorm + linear (round 5) against row statistics + 
         emit(case="lnfold", shape=f"{name} {M}x{N}x{K} {act}", us={k: round(v, 1) for k, v in us.items()},
              old=round(us["ln"] + us["gemm"], 1), new=round(us["stats"] + us["gemm_rs"], 1))
         del x, xn, out
+
+if "expand" in verbs:   # the per-head K = 64 "expand" product of the absorbed SVA path: gemm_k64 vs the 128-tile kernel (CMB_GEMM_K64=0 build env)
+    Bq, heads, hd, Cin = B * 576, 16, 64, 1024
+    x, wt = rn(Bq, heads * hd), rn(Cin, heads * hd, scale=0.05)
+    U = torch.empty(Bq, heads, Cin, device=dev, dtype=bf)
+    f = lambda: ops.k_gemm_batched(x, wt, U, batch=heads, M=Bq, N=Cin, K=hd, lda=heads * hd, ldb=heads * hd, ldc=heads * Cin, a_bs=hd, b_bs=hd, c_bs=Cin)  # noqa: E731
+    f()
+    want = torch.einsum("qhj,chj->qhc", x[:2048].float().view(-1, heads, hd), wt.float().view(Cin, heads, hd))
+    err = float((U[:2048].float() - want).abs().max() / want.abs().max())
+    us = time_variants({"k": f}, iters=20)["k"]
+    emit(case="expand", shape=f"{Bq}x{heads}x{Cin} K={hd}", kernel=L.load().cmb_gemm_last_kernel(), us=round(us, 1),
+         write_tbps=round(U.numel() * 2 / us / 1e6, 2), rel_err=err)
