@@ -13,6 +13,7 @@
 //   * block id -> tile mapping is XCD-aware (8 XCDs, private L2s).
 //   * rows of A / C / residual / pre_out go through a 3-level row map so gathers such as the in-LLM
 //     slice hidden[:, 91:691].view(B,24,25,H)[:, :, :24] are folded into the loads.
+#include <cstdio>
 #include <stdlib.h>
 #include "gemm_common.h"
 
@@ -375,11 +376,11 @@ static int tail_split_rows(const GemmParams& p, int splits, int hint) {
   return m1;
 }
 
+// descriptor -> parameter block: the checks and the split-K geometry of one cmb_gemm call (shared by cmb_gemm and cmb_gemm_pair)
 template <typename T>
-int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
+int gemm_params_from_desc(const cmb_gemm_desc* d, GemmParams& p, int& splits) {
   constexpr int BK = 128 / (int)sizeof(T);
   if (d->K % BK != 0 || d->N % 8 != 0) return CMB_ERR_SHAPE;
-  GemmParams p;
   p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
   p.A = (const char*)d->A; p.a_map = make_rowmap(d->a_map);
   p.B = (const char*)d->B; p.ldb = d->ldb;
@@ -396,7 +397,7 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
   p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
   p.slab_rows = p.M;
   p.row_mean = d->row_mean; p.row_rstd = d->row_rstd; p.col_sum = d->col_sum;
-  int splits = d->split_k > 1 ? d->split_k : 1;
+  splits = d->split_k > 1 ? d->split_k : 1;
   if (d->row_mean && (!d->row_rstd || !d->col_sum || !d->bias || d->alpha != 1.0f || splits > 1 || p.batch > 1 || sizeof(T) != 2 ||
                       d->pre_out))
     return CMB_ERR_BAD_ARG;   // the folded-LayerNorm epilogue: bf16 operands, bias (b'), one launch over the whole K
@@ -431,6 +432,17 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
     } else {
       p.k_per_split = p.K;
     }
+  }
+  return CMB_OK;
+}
+
+template <typename T>
+int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
+  GemmParams p;
+  int splits = 1;
+  {
+    const int prc = gemm_params_from_desc<T>(d, p, splits);
+    if (prc != CMB_OK) return prc;
   }
   int rc;
   if constexpr (sizeof(T) == 2) {
@@ -575,6 +587,7 @@ extern "C" int cmb_gemm_policy_clear(void) {
 }
 
 extern "C" int cmb_gemm_last_kernel(void) { return g_last_kernel; }
+extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream);
 
 extern "C" int64_t cmb_gemm_tail_rows(int64_t M, int64_t N) { return tail_split_rows_mnk(M, N); }
 
@@ -583,6 +596,61 @@ extern "C" int cmb_gemm_tn(const cmb_gemm_desc* d, void* stream) {
   if (d->M <= 0 || d->N <= 0 || d->K < 0) return CMB_ERR_BAD_ARG;
   return gemm_tn_dispatch(d, (hipStream_t)stream);
 }
+
+static int g_last_pair = 0;   // cmb_gemm_pair: did the last call take the one-launch path?
+
+// Two independent bf16 GEMMs.  One launch of the persistent 256 x 256 kernel with the workgroups split between the problems
+// (gemm_p5.hip, P5Args) when both would take that kernel on their own with their whole K, the same activation template and no
+// tail split, and the round arithmetic says the pair saves at least 4 % (DINOv2's and SigLIP's 1.62- / 1.35-round linears
+// side by side: 3.0 + 2.9 rounds on 138 + 118 workgroups instead of 2 + 2 on 256); otherwise exactly the two cmb_gemm calls.
+// Results are bit-identical either way (same kernel, same item arithmetic).  CMB_GEMM_PAIR=0 forces the two calls (A/B runs).
+extern "C" int cmb_gemm_pair(const cmb_gemm_desc* d0, const cmb_gemm_desc* d1, void* stream) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("CMB_GEMM_PAIR");
+    enabled = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  g_last_pair = 0;
+  hipStream_t s = (hipStream_t)stream;
+  auto simple = [](const cmb_gemm_desc* d) {
+    return d && d->A && d->B && d->C && d->M > 0 && d->N > 0 && d->K > 0 && d->dtype == CMB_BF16 && d->out_dtype == CMB_BF16 &&
+           d->split_k <= 1 && d->batch <= 1 && !d->pre_out && !d->tile_hint && !d->row_mean;
+  };
+  static int debug = -1;
+  if (debug < 0) debug = getenv("CMB_GEMM_PAIR_DEBUG") ? 1 : 0;
+  if (enabled && simple(d0) && simple(d1) && d0->act == d1->act) {
+    GemmParams p0, p1;
+    int s0 = 1, s1 = 1;
+    const int r0 = gemm_params_from_desc<bf16_t>(d0, p0, s0), r1 = gemm_params_from_desc<bf16_t>(d1, p1, s1);
+    if (r0 == CMB_OK && r1 == CMB_OK && s0 == 1 && s1 == 1) {
+      // legal on the persistent kernel (whatever the single-launch cost model would pick: a tail split or the 128-tile kernel
+      // are answers to the same partly filled rounds the pair fills)
+      auto legal = [](const GemmParams& p) {
+        const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        return p.N % 128 == 0 && !p.P && tiles >= 64 && p5_ok(p, 1) && tile_span_fits_u32(p.a_map, p.ldb) && !tile_override();
+      };
+      const int t0 = 0, t1 = 0;
+      const int k0 = legal(p0) ? 2590 : 0, k1 = legal(p1) ? 2590 : 0;
+      const double gain = gemm_p5_pair_gain(p0, p1, device_cus());
+      if (debug) fprintf(stderr, "cmb_gemm_pair: legal %d %d gain %.3f\n", k0, k1, gain);
+      if (!t0 && !t1 && k0 == 2590 && k1 == 2590 && gain >= 0.04) {
+        g_last_kernel = 2590;
+        const int rc = launch_gemm_p5_bf16(p0, 1, s, &p1);
+        if (rc == CMB_OK) g_last_pair = 1;
+        return rc;
+      }
+    } else if (debug) {
+      fprintf(stderr, "cmb_gemm_pair: params rc %d %d splits %d %d\n", r0, r1, s0, s1);
+    }
+  } else if (debug) {
+    fprintf(stderr, "cmb_gemm_pair: not simple (enabled %d, %d %d, act %d %d)\n", enabled, (int)simple(d0), (int)simple(d1),
+            d0 ? d0->act : -1, d1 ? d1->act : -1);
+  }
+  const int rc = cmb_gemm(d0, stream);
+  return rc != CMB_OK ? rc : cmb_gemm(d1, stream);
+}
+
+extern "C" int cmb_gemm_pair_last(void) { return g_last_pair; }
 
 extern "C" int cmb_gemm(const cmb_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return CMB_ERR_BAD_ARG;

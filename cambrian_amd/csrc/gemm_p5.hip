@@ -19,6 +19,7 @@
 //
 // LDS tile layout (gemm_layout.h): rows of 128 B = 8 chunks of 16 B; chunk c of row r lives at r*128 + ((c ^ gl_swz(r)) << 4);
 // ds_read_b128 fragment reads are conflict-free and the swizzle is applied to the DMA's per-lane SOURCE address.
+#include <cstdlib>
 #include <type_traits>
 #include "gemm_common.h"
 
@@ -203,9 +204,26 @@ struct P5Src {
   const char* b_base;
 };
 
-template <int ACT>
-__global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, const int n_items) {
+// Pair launch (round 6): TWO independent problems with the same activation template in one grid — workgroups [0, g0) run
+// problem 0, the rest problem 1, each side persistent over its own items exactly as a single launch of that many workgroups.
+// DINOv2's and SigLIP's linears at 24 images are 414 / 345 tiles: 1.62 / 1.35 rounds of 256 workgroups, i.e. two rounds each
+// for 2.97 rounds of work; side by side on 138 + 118 workgroups they are 3.0 + 2.9 rounds (gemm.hip: cmb_gemm_pair picks g0).
+// A workgroup picks its problem ONCE: everything below reads `p` through one reference as before.
+struct P5Args {
+  GemmParams prob[2];
+  int n_items[2];
+  int g0;   // workgroups of problem 0 (single launches: the whole grid)
+};
+
+// PAIR = false is the single launch: problem 0 at fixed kernel-argument offsets, exactly the code of rounds 2-5.  (One
+// instantiation for both, `p` chosen at run time, made every single launch 1-5 % slower — the parameter block is then read with
+// scalar loads item by item instead of living in registers: profiles/r06_lab.md.)
+template <int ACT, bool PAIR>
+__global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const P5Args args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int side = PAIR && (int)blockIdx.x >= args.g0 ? 1 : 0;
+  const GemmParams& p = PAIR ? args.prob[side] : args.prob[0];
+  const int n_items = PAIR ? args.n_items[side] : args.n_items[0];
   typedef bf16x8_t frag_t;
   typedef std::integral_constant<int, 0> I0;
   typedef std::integral_constant<int, 1> I1;
@@ -215,8 +233,8 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int stride = (int)gridDim.x;
-  const int first_item = (int)blockIdx.x;
+  const int stride = !PAIR ? (int)gridDim.x : side ? (int)gridDim.x - args.g0 : args.g0;
+  const int first_item = side ? (int)blockIdx.x - args.g0 : (int)blockIdx.x;
   const int last_item = first_item + ((n_items - 1 - first_item) / stride) * stride;
 
   // ---- DMA side -------------------------------------------------------------------------------------------------
@@ -388,15 +406,44 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const GemmParams p, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
+// Workgroups of problem 0 in a pair launch: the split g0 in [1, n_cu) that minimises max over the two sides of
+// rounds x (K tiles per item + epilogue), rounds = ceil(items / workgroups) (whole XCD multiples are not needed: a side's items
+// are numbered from its own first workgroup).
+int p5_pair_split(int items0, int k0, int items1, int k1, int n_cu) {
+  const double c0 = k0 / 64.0 + 6.0, c1 = k1 / 64.0 + 6.0;
+  int best = n_cu / 2;
+  double best_t = 1e30;
+  static int step = 0;   // CMB_P5_PAIR_ALIGN (lab): candidate splits in multiples of this (8 keeps item % 8 == block % 8 on both sides)
+  if (!step) {
+    const char* e = getenv("CMB_P5_PAIR_ALIGN");
+    step = e && atoi(e) > 0 ? atoi(e) : 1;
+  }
+  for (int g = 8; g <= n_cu - 8; g += step) {
+    const double t0 = (double)((items0 + g - 1) / g) * c0, t1 = (double)((items1 + (n_cu - g) - 1) / (n_cu - g)) * c1;
+    const double t = t0 > t1 ? t0 : t1;
+    if (t < best_t - 1e-9) best_t = t, best = g;
+  }
+  return best;
+}
+double p5_pair_cost(int items0, int k0, int items1, int k1, int n_cu, bool paired) {
+  const double c0 = k0 / 64.0 + 6.0, c1 = k1 / 64.0 + 6.0;
+  if (!paired) return (double)((items0 + n_cu - 1) / n_cu) * c0 + (double)((items1 + n_cu - 1) / n_cu) * c1;
+  const int g = p5_pair_split(items0, k0, items1, k1, n_cu);
+  const double t0 = (double)((items0 + g - 1) / g) * c0, t1 = (double)((items1 + (n_cu - g) - 1) / (n_cu - g)) * c1;
+  return t0 > t1 ? t0 : t1;
+}
+
 template <int ACT>
-int launch_p5_act(GemmParams& p, int splits, hipStream_t s) {
+int launch_p5_act(GemmParams& p, int splits, hipStream_t s, GemmParams* q = nullptr) {
   constexpr int smem = 2 * kP5Buf + 4 * 8192;  // two operand buffers + the epilogue's staging area = all 160 KiB
   static bool attr_done = false;
   static int n_cu = 0;
-  auto kern = gemm_nt_p5_kernel<ACT>;
+  auto kern = gemm_nt_p5_kernel<ACT, false>;
+  auto kern2 = gemm_nt_p5_kernel<ACT, true>;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-        hipSuccess)
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return CMB_ERR_LAUNCH;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -409,23 +456,51 @@ int launch_p5_act(GemmParams& p, int splits, hipStream_t s) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
   const int n_items = p.tiles_m * p.tiles_n * splits;
-  const int grid = n_items < n_cu ? n_items : n_cu;
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, p, n_items);
+  int g0 = n_items < n_cu ? n_items : n_cu;
+  int grid = g0;
+  P5Args args;
+  args.prob[0] = p;
+  args.n_items[0] = n_items;
+  if (q) {   // pair launch: q on the workgroups [g0, n_cu)
+    q->tiles_m = (q->M + 255) / 256;
+    q->tiles_n = (q->N + 255) / 256;
+    args.prob[1] = *q;
+    args.n_items[1] = q->tiles_m * q->tiles_n;
+    g0 = p5_pair_split(n_items, p.K, args.n_items[1], q->K, n_cu);
+    if (const char* e = getenv("CMB_P5_PAIR_G0")) {   // lab: sweep the split
+      const int v = atoi(e);
+      if (v >= 8 && v <= n_cu - 8) g0 = v;
+    }
+    grid = n_cu;
+  } else {
+    args.prob[1] = p;
+    args.n_items[1] = 0;
+  }
+  args.g0 = g0;
+  if (q) hipLaunchKernelGGL(kern2, dim3((unsigned)grid), dim3(256), smem, s, args);
+  else hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, args);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }
 
 }  // namespace
 
-int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s) {
+int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s, GemmParams* q) {
   switch (p.slabs ? CMB_ACT_NONE : p.act) {
-    case CMB_ACT_GELU_ERF: return launch_p5_act<CMB_ACT_GELU_ERF>(p, splits, s);
-    case CMB_ACT_GELU_TANH: return launch_p5_act<CMB_ACT_GELU_TANH>(p, splits, s);
-    case CMB_ACT_QUICK_GELU: return launch_p5_act<CMB_ACT_QUICK_GELU>(p, splits, s);
-    case CMB_ACT_SILU: return launch_p5_act<CMB_ACT_SILU>(p, splits, s);
-    case CMB_ACT_SWIGLU_PAIRS: return launch_p5_act<CMB_ACT_SWIGLU_PAIRS>(p, splits, s);
-    default: return launch_p5_act<CMB_ACT_NONE>(p, splits, s);
+    case CMB_ACT_GELU_ERF: return launch_p5_act<CMB_ACT_GELU_ERF>(p, splits, s, q);
+    case CMB_ACT_GELU_TANH: return launch_p5_act<CMB_ACT_GELU_TANH>(p, splits, s, q);
+    case CMB_ACT_QUICK_GELU: return launch_p5_act<CMB_ACT_QUICK_GELU>(p, splits, s, q);
+    case CMB_ACT_SILU: return launch_p5_act<CMB_ACT_SILU>(p, splits, s, q);
+    case CMB_ACT_SWIGLU_PAIRS: return launch_p5_act<CMB_ACT_SWIGLU_PAIRS>(p, splits, s, q);
+    default: return launch_p5_act<CMB_ACT_NONE>(p, splits, s, q);
   }
+}
+
+// cost model of a pair launch against the two single launches (K tiles + epilogue per item, whole rounds): > 0 = the pair wins
+double gemm_p5_pair_gain(const GemmParams& a, const GemmParams& b, int n_cu) {
+  const int ia = ((a.M + 255) / 256) * ((a.N + 255) / 256), ib = ((b.M + 255) / 256) * ((b.N + 255) / 256);
+  const double single = p5_pair_cost(ia, a.K, ib, b.K, n_cu, false), pair = p5_pair_cost(ia, a.K, ib, b.K, n_cu, true);
+  return (single - pair) / single;
 }
 
 }  // namespace cmb_gemm_detail

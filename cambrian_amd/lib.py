@@ -25,7 +25,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
 KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS, KNOB_LN_MULTI_CHUNK, KNOB_FLASH = 0, 1, 2, 3, 4, 5   # enum cmb_knob_id
-ABI_VERSION = 7   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
+ABI_VERSION = 8   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
           -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
@@ -145,6 +145,8 @@ SIGNATURES = {
     "cmb_knob_get": (C.c_int, [_i32]),
     "cmb_gemm": (C.c_int, [C.POINTER(GemmDesc), _p]),
     "cmb_gemm_tn": (C.c_int, [C.POINTER(GemmDesc), _p]),
+    "cmb_gemm_pair": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), _p]),
+    "cmb_gemm_pair_last": (C.c_int, []),
     "cmb_gemm_tile": (C.c_int, [C.c_int, _i64, _i64, _i32, _i32]),
     "cmb_gemm_last_kernel": (C.c_int, []),
     "cmb_gemm_policy_set": (C.c_int, [_i64, _i64, _i64, _i32, _i32]),
@@ -213,12 +215,17 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C cambrian_amd/csrc`.  There is no PyTorch fallback for the hot path.")
         lib = C.CDLL(LIB_PATH)
+        # lab only (tools/r06_lab.py, same-box A/B of an OLDER build of the library given by CAMBRIAN_AMD_LIB): entry points the
+        # old build lacks stay unbound and its ABI revision is accepted — the caller uses only what both builds share
+        lenient = bool(os.environ.get("CAMBRIAN_AMD_LIB")) and os.environ.get("CAMBRIAN_AMD_LIB_LENIENT") == "1"
         for name, (res, args) in SIGNATURES.items():
+            if lenient and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
         got = lib.cmb_abi_version()
-        if got != ABI_VERSION:
+        if got != ABI_VERSION and not lenient:
             raise CambrianAmdError(
                 f"{LIB_PATH} reports ABI revision {got}, this binding is written against {ABI_VERSION}: every symbol of a "
                 "stale build still resolves but argument lists have shifted — rebuild it (`make -C cambrian_amd/csrc`)")

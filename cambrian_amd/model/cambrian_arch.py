@@ -41,6 +41,33 @@ STATIC_PATH = True
 _TOWER_STREAMS = os.environ.get("CAMBRIAN_AMD_TOWER_STREAMS", "0")   # frozen towers on side HIP streams (encode_images)
 
 
+_PAIR_TOWERS = os.environ.get("CAMBRIAN_AMD_PAIR_TOWERS", "1") != "0"   # two frozen ViT trunks in lock-step (encode_images)
+
+
+def _pair_rounds_gain(ta, tb, batch: int, n_cu: int = 256) -> float:
+    """Whole-round arithmetic of running trunks ``ta`` / ``tb`` (ViTTrunk) block by block side by side: K tiles + epilogue per
+    256 x 256 item, rounds = ceil(items / workgroups), for the two residual linears of a block (the launches forward_paired
+    hands to cmb_gemm_pair, which repeats this arithmetic per call).  Returns the modelled time saved per common block in
+    item units (<= 0: do not pair)."""
+    def items(t, n_out):
+        cfg = t.cfg
+        rows = batch * (cfg.num_patches + (1 if cfg.has_cls else 0))
+        return -(-rows // 256) * -(-n_out // 256)
+
+    def best_pair(i0, c0, i1, c1):
+        best = float("inf")
+        for g in range(8, n_cu - 7):
+            best = min(best, max(-(-i0 // g) * c0, -(-i1 // (n_cu - g)) * c1))
+        return best
+
+    gain = 0.0
+    for k_of in (lambda c: c.hidden_size, lambda c: c.mlp_dim):   # contraction depth of proj / fc2
+        (ia, ca), (ib, cb) = [(items(t, t.cfg.hidden_size), k_of(t.cfg) / 64.0 + 6.0) for t in (ta, tb)]
+        single = -(-ia // n_cu) * ca + -(-ib // n_cu) * cb
+        gain += max(0.0, single - best_pair(ia, ca, ib, cb))
+    return gain
+
+
 def _tower_stream_plan(n: int):
     """CAMBRIAN_AMD_TOWER_STREAMS: "0" = every tower on the launch stream (None); "1" = one side stream per tower; else one
     character per tower in list order — equal characters share a side stream (and run one after the other on it), "0" keeps
@@ -272,7 +299,7 @@ class CambrianMetaForCausalLM(ABC):
         plan = _tower_stream_plan(len(towers))
         if (plan is None or len(towers) < 2 or not frozen or not image_aux_list[0].is_cuda
                 or torch.is_grad_enabled() and any(x.requires_grad for x in image_aux_list)):
-            return [tower(image_aux) for image_aux, tower in zip(image_aux_list, towers)]
+            return self._encode_images_one_stream(image_aux_list, towers, frozen)
         main = torch.cuda.current_stream()
         pool = getattr(self, "_tower_streams", None)
         if pool is None:
@@ -295,6 +322,41 @@ class CambrianMetaForCausalLM(ABC):
                 outs[i] = towers[i](image_aux_list[i])
         for st in used:
             main.wait_stream(st)
+        return outs
+
+    def _encode_images_one_stream(self, image_aux_list, towers, frozen):
+        """Every tower on the launch stream.  Round 6: the two frozen ViT trunks whose blocks gain most from running side by
+        side (DINOv2 and SigLIP at the release sizes: 1.62- and 1.35-round linears) advance in lock-step and hand their
+        same-position residual linears to cmb_gemm_pair — one launch with the workgroups split between the two problems
+        (vit.py::forward_paired).  The towers' own post-processing (interpolation, dtype) follows per tower as before;
+        CAMBRIAN_AMD_PAIR_TOWERS=0 runs them one after the other."""
+        from .multimodal_encoder.vit import ViTTrunk, forward_paired
+        pair = None
+        if (_PAIR_TOWERS and frozen and image_aux_list[0].is_cuda and not isinstance(image_aux_list[0], list)
+                and image_aux_list[0].dtype == torch.bfloat16):
+            cand = [i for i, t in enumerate(towers)
+                    if isinstance(getattr(t, "vision_tower", None), ViTTrunk) and "trunk_out" in t._forward.__code__.co_varnames
+                    and not isinstance(image_aux_list[i], list) and not t.vision_tower._ln_fused]
+            best = 0.0
+            for x in range(len(cand)):
+                for y in range(x + 1, len(cand)):
+                    i, j = cand[x], cand[y]
+                    gain = _pair_rounds_gain(towers[i].vision_tower, towers[j].vision_tower, image_aux_list[i].shape[0])
+                    if gain > best:
+                        best, pair = gain, (i, j)
+        outs = [None] * len(towers)
+        for k, (image_aux, tower) in enumerate(zip(image_aux_list, towers)):
+            if pair is not None and k == pair[1]:
+                continue                                  # produced together with pair[0]
+            if pair is not None and k == pair[0]:
+                i, j = pair
+                ta, tb = towers[i], towers[j]
+                xa, xb = image_aux_list[i].to(device=ta.device), image_aux_list[j].to(device=tb.device)
+                sa, sb = forward_paired(ta.vision_tower, xa, tb.vision_tower, xb)
+                outs[i] = ta._forward(image_aux_list[i], trunk_out=sa)
+                outs[j] = tb._forward(image_aux_list[j], trunk_out=sb)
+            else:
+                outs[k] = tower(image_aux)
         return outs
 
     # ------------------------------------------------------------------------------------------

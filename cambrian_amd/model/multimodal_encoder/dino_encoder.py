@@ -122,9 +122,12 @@ class DinoVisionTower(BaseVisionTower):
         target = self._interp_size if self._interp_size is not None else image_features.shape[1]
         return self._resample(image_features, target)
 
-    def _forward(self, images):
+    def _forward(self, images, trunk_out=None):
+        """``trunk_out``: the trunk's output for ``images`` when the caller has already run it (the paired tower launch of
+        encode_images); the wrapper's own steps follow unchanged."""
         with self._grad_mode():  # dino_encoder.py:158
-            feats = self.interpolate(self.feature_select(self.vision_tower(images.to(device=self.device))))
+            seq = self.vision_tower(images.to(device=self.device)) if trunk_out is None else trunk_out
+            feats = self.interpolate(self.feature_select(seq))
             return feats.to(images.dtype) if images.dtype in (torch.float32, torch.bfloat16) else feats
 
     @property

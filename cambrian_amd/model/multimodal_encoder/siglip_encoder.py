@@ -96,7 +96,10 @@ class SiglipVisionTower(ClipVisionTower):
                                                 height=self._image_size, width=self._image_size, image_mean=[0.5] * 3)
         self.is_loaded = True
 
-    def _forward(self, images, interpolate_token=576):
+    def _forward(self, images, interpolate_token=576, trunk_out=None):
+        """``trunk_out``: the trunk's output for ``images`` when the caller has already run it (the paired tower launch of
+        encode_images)."""
         with self._grad_mode():  # siglip_encoder.py:96
-            feats = self.interpolate(self.vision_tower(images.to(device=self.device)))
+            seq = self.vision_tower(images.to(device=self.device)) if trunk_out is None else trunk_out
+            feats = self.interpolate(seq)
             return feats.to(images.dtype) if images.dtype in (torch.float32, torch.bfloat16) else feats

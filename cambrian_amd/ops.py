@@ -55,7 +55,7 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
            out: Optional[torch.Tensor] = None, c_map: Optional[RowMap] = None, out_dtype: Optional[torch.dtype] = None,
            pre_out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0,
            split_k: int = 1, tile: int = 0, row_stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-           col_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+           col_sum: Optional[torch.Tensor] = None, _collect: Optional[list] = None) -> torch.Tensor:
     """C[M,N] = epilogue(alpha * A[M,K] @ W[N,K]^T).  ``a`` is [M,K] (row stride a.stride(0)) unless an
     explicit ``a_map``/``M`` is given, in which case ``a`` is just the base tensor.  ``row_stats`` = (mean, rstd) [M] fp32
     of ``k_row_stats`` + ``col_sum`` [N]: the LayerNorm in front of this linear folded into its epilogue
@@ -129,6 +129,9 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
     if GEMM_CENSUS is not None and dt == torch.bfloat16 and split_k <= 1 and tile == 0:
         key = (M, N, K, act, pre_out is not None)
         GEMM_CENSUS[key] = GEMM_CENSUS.get(key, 0) + 1
+    if _collect is not None:   # k_gemm_pair: the descriptor (and what it points into) instead of the launch
+        _collect.append((d, out, (a, w, bias, colscale, residual, pre_out, ws, row_stats, col_sum), (M, N, K, act, dt, split_k, tile)))
+        return out
     prof = GEMM_PROFILE
     tile_used = 0
     if prof is not None:  # HIP events on the launch stream around this launch (bench.py roofline leg)
@@ -146,6 +149,33 @@ def k_gemm(a: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, a_map: 
         prof.append((e0, e1, 2.0 * M * N * K, dt, split_k, tile_used, (M, N, K, act, out.dtype == torch.float32),
                      L.load().cmb_gemm_last_kernel()))
     return out
+
+
+def k_gemm_pair(kw0: dict, kw1: dict) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Two independent ``k_gemm`` calls (keyword dicts with ``a`` and ``w``) through ``cmb_gemm_pair``: ONE launch of the
+    persistent 256 x 256 kernel with the workgroups split between the problems when the library's round arithmetic says it pays
+    (DINOv2's and SigLIP's same-position linears), else the two launches; the results are bit-identical either way."""
+    col: list = []
+    k_gemm(_collect=col, **kw0)
+    k_gemm(_collect=col, **kw1)
+    (d0, o0, _k0, m0), (d1, o1, _k1, m1) = col
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib = L.load()
+    rc = lib.cmb_gemm_pair(C.byref(d0), C.byref(d1), L.stream_ptr(o0.device))
+    L.check(rc, f"cmb_gemm_pair({m0[:3]}, {m1[:3]})")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        paired = bool(lib.cmb_gemm_pair_last())
+        # one row for the call: the FLOPs of both problems over the span of the launch (or of the two launches)
+        prof.append((e0, e1, 2.0 * (m0[0] * m0[1] * m0[2] + m1[0] * m1[1] * m1[2]), m0[4], 1, 256,
+                     (m0[0], m0[1], m0[2], m0[3], False), lib.cmb_gemm_last_kernel(),
+                     ("pair:" if paired else "seq:") + f"{m1[0]}x{m1[1]}x{m1[2]}"))
+    return o0, o1
+
 
 
 def k_quantize_fp8_rows(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

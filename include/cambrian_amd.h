@@ -66,7 +66,7 @@ const char* cmb_version(void);
  * the kernel-selection knobs of round 4 = 5).  Bindings must compare it with the revision they
  * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
  * library still resolves, and a shifted argument list corrupts memory instead of failing. */
-#define CMB_ABI_VERSION 7
+#define CMB_ABI_VERSION 8
 int cmb_abi_version(void);
 
 /* Run-time kernel-selection knobs: which of several kernels that compute the SAME function an entry point launches
@@ -154,6 +154,16 @@ typedef struct cmb_gemm_desc {
 } cmb_gemm_desc;
 
 int cmb_gemm(const cmb_gemm_desc* d, void* stream);
+/* Two INDEPENDENT bf16 products in one call (round 6): the same results as cmb_gemm(d0) followed by cmb_gemm(d1), bit for bit.
+ * When both would run on the persistent 256 x 256 kernel with their whole K, the same `act`, no batch / split_k / pre_out /
+ * tile_hint / folded LayerNorm, and whole-round arithmetic says it pays, they leave as ONE launch whose workgroups are split
+ * between the two problems — the frozen ViT towers' same-position linears (DINOv2 17520 x 1536 x {1536, 4096} beside SigLIP
+ * 17496 x 1152 x {1152, 4352} at 24 images: 1.62 and 1.35 rounds of 256 workgroups each, 3.0 + 2.9 rounds on 138 + 118 side by
+ * side; HF / timm blocks behind dino_encoder.py:156-165, siglip_encoder.py:95-99, towers independent: cambrian_arch.py:271-278).
+ * Otherwise the two calls are made one after the other.  cmb_gemm_pair_last() = 1 if the calling thread's last cmb_gemm_pair
+ * took the one-launch path.  CMB_GEMM_PAIR=0 in the environment forces two launches (A/B runs). */
+int cmb_gemm_pair(const cmb_gemm_desc* d0, const cmb_gemm_desc* d1, void* stream);
+int cmb_gemm_pair_last(void);
 /* C[M,N] = alpha * At[K,M]^T * Bt[K,N] (+ beta * C): the weight-gradient product dW = g^T x of every trainable linear of
  * the path (autograd's addmm on a transposed view in the reference: the SVA projections vision_sampler.py:159-189, the
  * projectors cambrian_arch.py:49-56), with BOTH operands row-major over the contraction rows as the activations lie in

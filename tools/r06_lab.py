@@ -193,3 +193,25 @@ if "expand" in verbs:   # the per-head K = 64 "expand" product of the absorbed S
     us = time_variants({"k": f}, iters=20)["k"]
     emit(case="expand", shape=f"{Bq}x{heads}x{Cin} K={hd}", kernel=L.load().cmb_gemm_last_kernel(), us=round(us, 1),
          write_tbps=round(U.numel() * 2 / us / 1e6, 2), rel_err=err)
+
+if "pair" in verbs:   # cmb_gemm_pair: DINOv2's and SigLIP's same-position residual linears as one launch vs two (bit-equal results)
+    lib = L.load()
+    cases = [("proj", (B * 730, 1536, 1536, True), (B * 729, 1152, 1152, False)),
+             ("fc2", (B * 730, 1536, 4096, True), (B * 729, 1152, 4304 if False else 4352, False))]
+    for name, (M0, N0, K0, ls0), (M1, N1, K1, ls1) in cases:
+        def mk(M, N, K, ls):
+            return dict(a=rn(M, K), w=rn(N, K, scale=K ** -0.5), bias=rn(N, dtype=f32), colscale=rn(N, dtype=f32) if ls else None,
+                        residual=rn(M, N), out=torch.empty(M, N, device=dev, dtype=bf))
+        k0, k1 = mk(M0, N0, K0, ls0), mk(M1, N1, K1, ls1)
+        ops.k_gemm(**k0); ops.k_gemm(**k1)
+        r0, r1 = k0["out"].clone(), k1["out"].clone()
+        k0["out"].zero_(); k1["out"].zero_()
+        ops.k_gemm_pair(k0, k1)
+        paired = int(lib.cmb_gemm_pair_last())
+        same = bool(torch.equal(k0["out"], r0) and torch.equal(k1["out"], r1))
+        us = time_variants({"two": lambda: (ops.k_gemm(**k0), ops.k_gemm(**k1)), "pair": lambda: ops.k_gemm_pair(k0, k1),
+                            "first": lambda: ops.k_gemm(**k0), "second": lambda: ops.k_gemm(**k1)}, iters=20)
+        fl = 2.0 * (M0 * N0 * K0 + M1 * N1 * K1)
+        emit(case="pair", shape=f"{name} {M0}x{N0}x{K0} + {M1}x{N1}x{K1}", paired=paired, bit_equal=same,
+             us={k: round(v, 1) for k, v in us.items()}, tflops={k: round(fl / us[k] / 1e6) for k in ("two", "pair")})
+        del k0, k1, r0, r1
