@@ -100,11 +100,13 @@ __global__ void __launch_bounds__(256) weight_prep_kernel(const cmb_prep_job one
 }
 
 // ---------------------------------------------------------------------------------------------
-// colsum: out[c] += sum_r in[r, c]  (fp32 atomics, one per column per block)
+// colsum: out[c] += sum_r in[r, c]  (fp32 atomics, one per column per block); with a row scale (cmb_colsum_scaled):
+// out[c] += sum_r scale[r, c / group] * in[r, c], group % 8 == 0 (the 8 columns of a lane share one factor)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ in, int64_t R, int64_t C, int64_t ld_in,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ out, int rows_per_block,
+                                                     const float* __restrict__ scale = nullptr, int64_t ld_scale = 0, int group = 8) {
   __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t cv = (int64_t)blockIdx.x * 64 + lane;  // vec8 column group
@@ -115,8 +117,14 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ in, i
     for (int64_t r = rbeg + wave; r < rend; r += 4) {
       float v[8];
       Vec8<T>::load(in + r * ld_in + cv * 8, v);
+      if (scale) {
+        const float f = scale[r * ld_scale + (cv * 8) / group];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(f, v[e], acc[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
     }
   }
 #pragma unroll
@@ -476,6 +484,18 @@ extern "C" int cmb_colsum(int dtype, const void* in, int64_t R, int64_t C, int64
   dim3 grid((unsigned)((C + 511) / 512), (unsigned)((R + rows_per_block - 1) / rows_per_block));
   DT_SWITCH(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C,
                                       ld_in, out, rows_per_block));
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+
+extern "C" int cmb_colsum_scaled(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in, const float* row_scale,
+                                 int64_t ld_scale, int32_t group, float* out, void* stream) {
+  if (!in || !out || !row_scale || R < 0 || C <= 0 || (C & 7) || group <= 0 || (group & 7) || C % group) return CMB_ERR_BAD_ARG;
+  if (R == 0) return CMB_OK;
+  const int rows_per_block = 256;
+  dim3 grid((unsigned)((C + 511) / 512), (unsigned)((R + rows_per_block - 1) / rows_per_block));
+  DT_SWITCH(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C, ld_in, out,
+                                      rows_per_block, row_scale, ld_scale, (int)group));
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }

@@ -155,6 +155,7 @@ SIGNATURES = {
     "cmb_quantize_fp8_rows": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
     "cmb_transpose": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "cmb_colsum": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _p]),
+    "cmb_colsum_scaled": (C.c_int, [C.c_int, _p, C.c_int64, C.c_int64, C.c_int64, _p, C.c_int64, C.c_int32, _p, _p]),
     "cmb_cast": (C.c_int, [C.c_int, _p, C.c_int, _p, _i64, _p]),
     "cmb_weight_prep_tiles": (_i64, [_i64, _i64]),
     "cmb_weight_prep_one": (C.c_int, [C.POINTER(PrepJob), _p]),

@@ -481,11 +481,20 @@ def k_gemm_tn(at: torch.Tensor, bt: torch.Tensor, *, out: Optional[torch.Tensor]
     return out
 
 
-def k_colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def k_colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+             group: int = 0) -> torch.Tensor:
+    """out[c] (+)= sum_r x[r, c]; with ``row_scale`` [R, C / group] fp32: sum_r row_scale[r, c // group] * x[r, c]."""
     L.require_gpu(x)
     R, Cc = x.shape
     if out is None:
         out = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+    if row_scale is not None:
+        if row_scale.dtype != torch.float32 or row_scale.dim() != 2 or row_scale.stride(1) != 1 or row_scale.shape != (R, Cc // group):
+            raise L.CambrianAmdError("colsum row_scale must be fp32 [R, C / group]")
+        rc = L.load().cmb_colsum_scaled(L.dtype_code(x.dtype), x.data_ptr(), R, Cc, x.stride(0), row_scale.data_ptr(),
+                                        row_scale.stride(0), group, out.data_ptr(), L.stream_ptr(x.device))
+        L.check(rc, "cmb_colsum_scaled")
+        return out
     rc = L.load().cmb_colsum(L.dtype_code(x.dtype), x.data_ptr(), R, Cc, x.stride(0), out.data_ptr(),
                              L.stream_ptr(x.device))
     L.check(rc, "cmb_colsum")
@@ -1348,9 +1357,9 @@ class SvaAbsorbedFn(torch.autograd.Function):
         L.check(L.load().cmb_sva_abs_bwd(C.byref(d), L.stream_ptr(dev)), "cmb_sva_abs_bwd")
         dbk = dbv = None
         if ctx.needs_input_grad[2]:   # d b_k[c] = sum_q d(cb)[q, h(c)] q[q, c]
-            dbk = (dcb[:, :, None] * q.view(Bq, 16, 64)).sum(0, dtype=torch.float32).reshape(1024).to(ctx.b_dtypes[0])
+            dbk = k_colsum(q, row_scale=dcb, group=64).to(ctx.b_dtypes[0])
         if ctx.needs_input_grad[3]:   # d b_v[c] = sum_q m3[q, h(c)] d out[q, c]
-            dbv = (m3[:, :, None] * dout.view(Bq, 16, 64)).sum(0, dtype=torch.float32).reshape(1024).to(ctx.b_dtypes[1])
+            dbv = k_colsum(dout, row_scale=m3, group=64).to(ctx.b_dtypes[1])
         return (dq, dU, dbk, dbv, dxhat, None, None, None, None, None, None, *dkvs)
 
 
@@ -1548,7 +1557,12 @@ class RmsNormForkFn(torch.autograd.Function):
             rc = L.load().cmb_rmsnorm_bwd_add(L.dtype_code(x2.dtype), gy.data_ptr(), x2.data_ptr(), L.ptr(gs), rows, D,
                                               w32.data_ptr(), rstd.data_ptr(), dx.data_ptr(), L.stream_ptr(x2.device))
             L.check(rc, "cmb_rmsnorm_bwd_add")
-        return dx.view(ctx.shape), dw, None
+        out = dx.view(ctx.shape)
+        # a buffer this call allocated and hands to exactly one receiver: whoever gets THIS object as its incoming gradient may
+        # write into it (ScatterQueryRowsFn.backward: no 400 MB clone per in-LLM SVA layer).  Autograd's own sums of several
+        # gradients are new tensors without the mark.
+        out._cmb_exclusive = True
+        return out, dw, None
 
 
 def rmsnorm_fork(x, weight, eps: float = 1e-6):
@@ -1672,7 +1686,9 @@ class ScatterQueryRowsFn(torch.autograd.Function):
         g = g.contiguous()
         drows = torch.empty((B * side * side, H), dtype=g.dtype, device=g.device)
         k_copy_rows(g.view(-1)[pos * H:], hook_row_map(S, H, side), drows, L.identity_map(H), B * side * side, H)
-        dh = g.clone()
+        # d(hidden) = g with the overwritten rows zeroed: in place when g is a buffer its producer marked as handed to this node
+        # alone (RmsNormForkFn.backward: the decoder layer that follows), else on a copy (round 6: the copy was 400 MB x 10 layers)
+        dh = g if getattr(g, "_cmb_exclusive", False) else g.clone()
         k_copy_rows(None, None, dh.view(-1)[pos * H:], hook_row_map(S, H, side), B * side * side, H)  # zero the rows
         if ctx.link is not None and ctx.link.get("armed") and ctx.needs_input_grad[0]:
             ctx.link["dh"] = dh  # the paired gather's backward completes it and returns it for `hidden`

@@ -207,6 +207,12 @@ int cmb_transpose(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in
 /* out[c] (fp32) += sum_r in[r, c]   — bias gradients (atomic accumulate; caller zero-fills). */
 int cmb_colsum(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in,
                float* out, void* stream);
+/* out[c] += sum_r row_scale[r * ld_scale + c / group] * in[r, c]  (fp32 accumulation; out must be zero-filled by the caller;
+ * group % 8 == 0, C % group == 0).  The bias gradients of the absorbed SVA projections: d b_k[c] = sum_q d(cb)[q, h(c)] q[q, c],
+ * d b_v[c] = sum_q m3[q, h(c)] d out[q, c] with group = 64 = one head (vision_sampler.py:187-189's k_proj / v_proj biases,
+ * restated per head: DESIGN.md section 4.5) — one pass over the rows instead of a broadcast product + reduction. */
+int cmb_colsum_scaled(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in, const float* row_scale,
+                      int64_t ld_scale, int32_t group, float* out, void* stream);
 
 /* y = (T)x elementwise casts between fp32 and bf16 (n elements). to_dtype/from_dtype are CMB_*. */
 int cmb_cast(int from_dtype, const void* in, int to_dtype, void* out, int64_t n, void* stream);

@@ -74,3 +74,48 @@ def test_hook_link_hidden_without_grad(dev):
     hidden2.sum().backward()
     assert "dh" not in link
     assert torch.allclose(w.grad, torch.tanh(q), atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("two_consumers", [False, True])
+def test_scatter_backward_writes_into_an_exclusive_gradient_buffer(dev, dt, two_consumers):
+    """Round 6: the gradient that RmsNormForkFn.backward allocates for the decoder layer's input is marked as handed to one
+    receiver, and ScatterQueryRowsFn.backward zeroes the overwritten rows IN it instead of in a 400 MB copy.  The gradients must
+    be those of plain indexing + a plain RMSNorm whether the mark arrives (one consumer) or autograd has summed two gradients
+    into a new, unmarked tensor (two consumers)."""
+    from cambrian_amd import ops
+    g = torch.Generator().manual_seed(5)
+    leaf0 = torch.randn(B * S * H, generator=g)
+    w_rows = torch.randn(B * SIDE * SIDE, H, generator=g).to(dev, dt)
+    w_norm = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dev, dt)
+    w_out = torch.randn(B, S, H, generator=g).to(dev, dt)
+    n = SIDE * (SIDE + 1)
+
+    def tail(hidden2, fused):
+        if fused:
+            skip, y = ops.rmsnorm_fork(hidden2, w_norm, 1e-6)
+        else:
+            skip, y = hidden2, hidden2 * torch.rsqrt(hidden2.float().pow(2).mean(-1, keepdim=True) + 1e-6).to(dt) * w_norm
+        loss = (y * w_out).sum() + (skip * 0.5).sum()
+        if two_consumers:
+            loss = loss + (hidden2 * 0.125).sum()
+        return loss
+
+    grads = {}
+    for name in ("ref", "ours"):
+        leaf = leaf0.to(dev, dt).requires_grad_(True)
+        hidden = (leaf * 1.5).view(B, S, H).clone()
+        if name == "ref":
+            blk = hidden[:, POS:POS + n].reshape(B, SIDE, SIDE + 1, H)
+            out = torch.tanh(blk[:, :, :SIDE].reshape(B * SIDE * SIDE, H)) * w_rows
+            new_blk = torch.cat([out.view(B, SIDE, SIDE, H), blk[:, :, SIDE:]], dim=2).reshape(B, n, H)
+            loss = tail(torch.cat([hidden[:, :POS], new_blk, hidden[:, POS + n:]], dim=1), fused=False)
+        else:
+            link = {}
+            out = torch.tanh(ops.gather_query_rows(hidden, POS, SIDE, link)) * w_rows
+            loss = tail(ops.scatter_query_rows(hidden, out, POS, SIDE, link), fused=True)
+        loss.backward()
+        grads[name] = leaf.grad.float().cpu()
+    tol = 2e-5 if dt == torch.float32 else 3e-2
+    d = (grads["ours"] - grads["ref"]).abs().max() / grads["ref"].abs().max()
+    assert d < tol, float(d)

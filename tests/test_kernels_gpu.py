@@ -660,3 +660,17 @@ def test_layernorm_bwd_multi_equals_layer_by_layer(dev, name, dt, L_, D, side, r
         if a is not None:
             assert rel_err(dadd[k], a.grad) < TOL[name]
             k += 1
+
+
+def test_colsum_scaled_matches_broadcast_product(dev):
+    """cmb_colsum_scaled: sum_r scale[r, c // 64] * x[r, c] — the bias gradients of the absorbed SVA projections (ops.py
+    SvaAbsorbedFn.backward) in one pass."""
+    import torch
+    from cambrian_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for R in (1, 777, 13824):
+        x = torch.randn(R, 1024, generator=g).to(dev, torch.bfloat16)
+        sc = torch.randn(R, 16, generator=g).to(dev)
+        got = ops.k_colsum(x, row_scale=sc, group=64)
+        want = (sc.double()[:, :, None] * x.double().view(R, 16, 64)).sum(0).reshape(1024)
+        assert ((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-6)).item() < 1e-5

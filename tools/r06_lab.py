@@ -215,3 +215,29 @@ if "pair" in verbs:   # cmb_gemm_pair: DINOv2's and SigLIP's same-position resid
         emit(case="pair", shape=f"{name} {M0}x{N0}x{K0} + {M1}x{N1}x{K1}", paired=paired, bit_equal=same,
              us={k: round(v, 1) for k, v in us.items()}, tflops={k: round(fl / us[k] / 1e6) for k in ("two", "pair")})
         del k0, k1, r0, r1
+
+if "lnmulti" in verbs:   # the 13 SVA layers' LayerNorm backwards of the 9216-token tower: knob LN_MULTI_CHUNK 4 / 7 / 104 / 107
+    rows, D, side, r, Ln = B * 9216, 1024, 96, 4, 13
+    x = rn(rows, D)
+    items = []
+    for l in range(Ln):
+        pos = rn(r * r, D, dtype=f32)
+        _, mean, rstd = ops.k_layernorm_fwd(x, None, None, 1e-5, add=pos, side=side, grid_r=r)
+        items.append((rn(rows, D), mean, rstd, pos, l))
+    acc = torch.zeros(rows, D, device=dev, dtype=f32)
+    ref = None
+    for chunk in (4, 7):   # (104 / 107 = d(pos) sums by ds_add_f32 in LDS: built, 3.5x slower, removed — profiles/r06_lab.md)
+        L.knob_set(L.KNOB_LN_MULTI_CHUNK, chunk)
+        dadd = [torch.zeros(r * r, D, device=dev) for _ in range(Ln)]
+        ops.k_layernorm_bwd_multi(x, items, side, r, acc, False, dadd)
+        got = (acc.clone(), torch.stack(dadd))
+        if ref is None:
+            ref = got
+        err = (float((got[0] - ref[0]).abs().max() / ref[0].abs().max()), float((got[1] - ref[1]).abs().max() / ref[1].abs().max()))
+        us4 = time_variants({"first4": lambda: ops.k_layernorm_bwd_multi(x, items[:4], side, r, acc, False, dadd),
+                             "all13": lambda: ops.k_layernorm_bwd_multi(x, items, side, r, acc, False, dadd)}, iters=6)
+        nl = -(-Ln // (chunk % 100))
+        emit(case="lnmulti", chunk=chunk, us={k: round(v, 1) for k, v in us4.items()}, rel_diff_vs_chunk4=err,
+             tbps_all13=round(rows * D * (2 * Ln + 2 * nl + 8 * nl - 4) / us4["all13"] / 1e6, 2),
+             tbps_first4=round(rows * D * (2 * 4 + 2 + 4) / us4["first4"] / 1e6, 2))
+    L.knob_set(L.KNOB_LN_MULTI_CHUNK, 4)
