@@ -451,6 +451,8 @@ int gemm_dispatch(const cmb_gemm_desc* d, hipStream_t s) {
     if (p.batch > 1) {
       if (gemm_k64_eligible(p)) g_last_kernel = 64, rc = launch_gemm_k64_batched(p, s);   // (CMB_GEMM_K64=0: the tile kernel)
       else g_last_kernel = 128, rc = launch_gemm<T, 128, 128, 2, 2>(p, 1, s);
+    } else if (!d->tile_hint && gemm_small_m_eligible(p, splits)) {
+      g_last_kernel = 32, rc = launch_gemm_small_m(p, s);
     } else if (m1) {
       GemmParams head = p, tail = p;
       head.M = m1;

@@ -193,6 +193,10 @@ double gemm_p5_pair_gain(const GemmParams& a, const GemmParams& b, int n_cu);
 bool gemm_k64_eligible(const GemmParams& p);
 int launch_gemm_k64_batched(const GemmParams& p, hipStream_t s);
 
+// gemm_smallm.hip: M <= 32 rows (the SVA layers' per-image context vectors): 32 output columns per workgroup, K split over its waves
+bool gemm_small_m_eligible(const GemmParams& p, int splits);
+int launch_gemm_small_m(const GemmParams& p, hipStream_t s);
+
 // gemm_tn.hip: C[M,N] = At[K,M]^T Bt[K,N] (both operands row-major over the contraction rows; p.a_map.s2 = lda, p.K = rows),
 // 128 x 128 tile, transposing LDS reads
 int launch_gemm_tn_bf16(GemmParams& p, int splits, hipStream_t s);

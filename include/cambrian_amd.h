@@ -184,7 +184,8 @@ int cmb_quantize_fp8_rows(int dtype, const void* x, int64_t ldx, int64_t rows, i
 int cmb_gemm_tile(int dtype, int64_t M, int64_t N, int32_t split_k, int32_t tile_hint);
 /* which kernel the calling thread's most recent cmb_gemm launched (0 before the first): 128 = 128x128 tile kernel,
  * 256 = 8-wave 256x256 kernel (gemm256.hip), 2590 = 4-wave register-buffered 256x256 kernel (gemm_nt_p5_kernel,
- * gemm_p5.hip), 1281 = cmb_gemm_tn's 128x128 kernel (gemm_tn.hip).  For labelling profiles and rooflines per kernel. */
+ * gemm_p5.hip), 1281 = cmb_gemm_tn's 128x128 kernel (gemm_tn.hip), 64 = the batched K = 64 kernel (gemm_k64.hip), 32 = the
+ * M <= 32 kernel (gemm_smallm.hip).  For labelling profiles and rooflines per kernel. */
 int cmb_gemm_last_kernel(void);
 /* Per-shape dispatch policy: bf16 launches of exactly (M, N, K, act) without a tile_hint and without split-K take
  * `kernel` (128 | 2560 = 8-wave 256x256 | 2590 = 4-wave 256x256; 0 removes the entry) instead of the built-in cost

@@ -112,3 +112,24 @@ def test_forward_paired_equals_sequential_trunks(dev):
     assert torch.equal(pa, ra) and torch.equal(pb, rb)
     pb2, pa2 = forward_paired(tb, xb, ta, xa)     # the shorter trunk first
     assert torch.equal(pa2, ra) and torch.equal(pb2, rb)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1024, 1024), (24, 1024, 1024), (32, 4096, 1024), (24, 96, 64), (7, 1024, 4096), (24, 1024, 192)])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_small_m_kernel(dev, M, N, K, odt):
+    """gemm_smallm.hip: M <= 32 rows (the SVA layers' per-image context vectors, vision_sampler.py:279-292) — 32 columns per
+    workgroup, K split over its four waves — against fp32 matmul of the same rounded operands and the 128-tile kernel."""
+    from cambrian_amd import lib as L
+    from cambrian_amd import ops
+    g = torch.Generator().manual_seed(M * 131 + N + K)
+    a_full = torch.randn(M, K + 64, generator=g).to(torch.bfloat16).to(dev)
+    a = a_full[:, :K]                                   # row stride != K
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    out = ops.k_gemm(a, w, out_dtype=odt)
+    assert L.load().cmb_gemm_last_kernel() == 32
+    ref = a.float() @ w.float().T
+    tol = 2e-5 if odt == torch.float32 else 8e-3
+    assert ((out.float() - ref).abs().max() / ref.abs().max()).item() < tol
+    out128 = ops.k_gemm(a, w, out_dtype=odt, tile=128)
+    assert L.load().cmb_gemm_last_kernel() == 128
+    assert ((out.float() - out128.float()).abs().max() / ref.abs().max()).item() < tol

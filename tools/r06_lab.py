@@ -241,3 +241,8 @@ if "lnmulti" in verbs:   # the 13 SVA layers' LayerNorm backwards of the 9216-to
              tbps_all13=round(rows * D * (2 * Ln + 2 * nl + 8 * nl - 4) / us4["all13"] / 1e6, 2),
              tbps_first4=round(rows * D * (2 * 4 + 2 + 4) / us4["first4"] / 1e6, 2))
     L.knob_set(L.KNOB_LN_MULTI_CHUNK, 4)
+
+if "smallm" in verbs:
+    a, w = rn(B, 1024), rn(1024, 1024, scale=1 / 32)
+    us = time_variants({"auto": lambda: ops.k_gemm(a, w), "tile128": lambda: ops.k_gemm(a, w, tile=128)}, iters=30)
+    emit(case="smallm", shape=f"{B}x1024x1024", us={k: round(v, 1) for k, v in us.items()})
