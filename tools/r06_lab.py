@@ -246,3 +246,15 @@ if "smallm" in verbs:
     a, w = rn(B, 1024), rn(1024, 1024, scale=1 / 32)
     us = time_variants({"auto": lambda: ops.k_gemm(a, w), "tile128": lambda: ops.k_gemm(a, w, tile=128)}, iters=30)
     emit(case="smallm", shape=f"{B}x1024x1024", us={k: round(v, 1) for k, v in us.items()})
+
+if "contract" in verbs:   # the per-head N = 64 "contract" product of the absorbed SVA path: gemm_n64 vs the 128-tile kernel (CMB_GEMM_N64=0 env)
+    Bq, heads, hd, Cin = B * 576, 16, 64, 1024
+    xb, w = rn(Bq, heads, Cin), rn(heads * hd, Cin, scale=1 / 32)
+    out = torch.empty(Bq, heads * hd, device=dev, dtype=bf)
+    f = lambda: ops.k_gemm_batched(xb.view(Bq, heads * Cin), w, out, batch=heads, M=Bq, N=hd, K=Cin, lda=heads * Cin, ldb=Cin, ldc=heads * hd, a_bs=Cin, b_bs=hd * Cin, c_bs=hd)  # noqa: E731
+    f()
+    want = torch.einsum("qhc,hjc->qhj", xb[:2048].float(), w.float().view(heads, hd, Cin)).reshape(2048, heads * hd)
+    err = float((out[:2048].float() - want).abs().max() / want.abs().max())
+    us = time_variants({"k": f}, iters=20)["k"]
+    emit(case="contract", shape=f"{Bq}x{heads}x{hd} K={Cin}", kernel=L.load().cmb_gemm_last_kernel(), us=round(us, 1),
+         read_tbps=round(xb.numel() * 2 / us / 1e6, 2), rel_err=err)
