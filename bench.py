@@ -381,7 +381,7 @@ PARITY = {
 
 
 ABSORB_KV_ON = False   # set in main(): whether the SVA layers take the absorbed K / V path (bf16 training default)
-PMC_FILES = {2590: "r04_pmc_gemm_p5.json", 256: "r03_pmc_gemm_8wave.json"}   # cmb_gemm_last_kernel id -> profiles/ file
+PMC_FILES = {2590: "r06_pmc_gemm_p5.json", 256: "r03_pmc_gemm_8wave.json"}   # cmb_gemm_last_kernel id -> profiles/ file
 
 
 def pmc_record(kernel_id):

@@ -3,6 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/cambrian_amd.h"
+#include <atomic>
+
+// "this kernel's dynamic-LDS attribute has been set" per DEVICE (hipFuncSetAttribute applies to the current device; a process-wide
+// bool left a second device of the process, or a first call racing on another thread, without it: ADVICE r5).  Setting an
+// attribute twice is harmless, so the flag only needs to be monotonic.
+struct CmbAttrOnce {
+  std::atomic<uint32_t> mask{0};
+  uint32_t need() {   // 0 = already done on the current device, else the device's bit
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    const uint32_t bit = 1u << (d & 31);
+    return (mask.load(std::memory_order_acquire) & bit) ? 0u : bit;
+  }
+  void done(uint32_t bit) { mask.fetch_or(bit, std::memory_order_release); }
+};
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

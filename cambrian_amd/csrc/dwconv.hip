@@ -321,12 +321,12 @@ template <typename T>
 int launch_dwconv_lds(const void* x, int64_t B, int H, int W, int C, const float* w, const float* bias, void* y,
                       hipStream_t s) {
   constexpr int smem = (8 + 6) * (16 + 6) * (64 * (int)sizeof(T) + 32) + 49 * 64 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7x7_lds_kernel<T>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 7) / 8;
   dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(C / 64), (unsigned)B);

@@ -469,8 +469,8 @@ __global__ void __launch_bounds__(256, 2) flash_dq2_kernel(const FlashParams p) 
 }  // namespace
 
 int launch_flash_fwd2(const FlashParams& p, bf16_t* out, float* lse, bool causal, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     bool ok = true;
 #define FWD2_ATTR(C_, M_)                                                                              \
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd2_kernel<C_, M_>),             \
@@ -478,7 +478,7 @@ int launch_flash_fwd2(const FlashParams& p, bf16_t* out, float* lse, bool causal
     FWD2_ATTR(true, true); FWD2_ATTR(true, false); FWD2_ATTR(false, false);
 #undef FWD2_ATTR
     if (!ok) return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   const int64_t nqb = p.S / 128;
   const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal) * p.H * p.B));   // 1-D: flash_map.h
@@ -491,8 +491,8 @@ int launch_flash_fwd2(const FlashParams& p, bf16_t* out, float* lse, bool causal
 
 
 int launch_flash_dq2(const FlashParams& p, bool causal, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     bool ok = true;
 #define DQ2_ATTR(C_, M_)                                                                              \
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dq2_kernel<C_, M_>),              \
@@ -500,7 +500,7 @@ int launch_flash_dq2(const FlashParams& p, bool causal, hipStream_t stream) {
     DQ2_ATTR(true, true); DQ2_ATTR(true, false); DQ2_ATTR(false, false);
 #undef DQ2_ATTR
     if (!ok) return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   const int64_t nqb = p.S / 128;
   const dim3 grid((unsigned)((int64_t)flash_items((int)nqb, causal) * p.H * p.B));

@@ -881,8 +881,8 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
   const int items = flash_items((int)nkb, causal != 0);
   const dim3 gq((unsigned)((int64_t)items * H * B)), gk((unsigned)((int64_t)items * HKV * B));   // 1-D: flash_map.h
   constexpr int smem = (2 * 64 * LDR + 2 * HD * LDT) * 2 + 128 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     bool ok = true;
 #define DKDV_ATTR(C_, M_, P_)                                                                                   \
   ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(flash_dkdv_kernel<C_, M_, P_, false>),           \
@@ -893,7 +893,7 @@ extern "C" int cmb_flash_attn_bwd(const void* q, const void* k, const void* v, c
     DKDV_ATTR(true, true, true); DKDV_ATTR(true, false, true); DKDV_ATTR(false, false, true);
 #undef DKDV_ATTR
     if (!ok) return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   // knob bits: 2 = dQ on LDS-DMA tiles (flash2.hip), 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body,
   // 16 = its transposed fragments by transposing reads; 0 = round 4  (bit 8, a dK/dV kernel on LDS-DMA tiles, is gone)

@@ -218,13 +218,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* slabs, 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_gemm(GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem = gemm_smem_bytes<BM, BN>();
-  static bool attr_done = false;
+  static CmbAttrOnce attr_once;
   auto kern = gemm_nt_kernel<T, BM, BN, WM, WN>;
-  if (!attr_done) {
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;

@@ -424,12 +424,12 @@ __global__ void __launch_bounds__(512) gemm_nt_256_kernel(const GemmParams p) {
 
 template <int SCHED>
 static int launch256(GemmParams& p, int splits, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<SCHED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) != hipSuccess)
       return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;

@@ -436,11 +436,11 @@ double p5_pair_cost(int items0, int k0, int items1, int k1, int n_cu, bool paire
 template <int ACT>
 int launch_p5_act(GemmParams& p, int splits, hipStream_t s, GemmParams* q = nullptr) {
   constexpr int smem = 2 * kP5Buf + 4 * 8192;  // two operand buffers + the epilogue's staging area = all 160 KiB
-  static bool attr_done = false;
+  static CmbAttrOnce attr_once;
   static int n_cu = 0;
   auto kern = gemm_nt_p5_kernel<ACT, false>;
   auto kern2 = gemm_nt_p5_kernel<ACT, true>;
-  if (!attr_done) {
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
             hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -451,7 +451,7 @@ int launch_p5_act(GemmParams& p, int splits, hipStream_t s, GemmParams* q = null
       return CMB_ERR_LAUNCH;
     n_cu -= n_cu % 8;  // whole XCD rounds: item % 8 == block % 8 in every round
     if (n_cu <= 0) return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;

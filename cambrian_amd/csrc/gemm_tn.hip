@@ -177,12 +177,12 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
 namespace cmb_gemm_detail {
 
 int launch_gemm_tn_bf16(GemmParams& p, int splits, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) !=
         hipSuccess)
       return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;

@@ -676,12 +676,12 @@ int launch_simple(const AbsParams& p, bool bwd, hipStream_t s) {
   const int64_t blocks = nq < 65535 ? nq : 65535;
   auto kf = sva_abs_simple_fwd_kernel<T>;
   auto kb = sva_abs_simple_bwd_kernel<T>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemSimple) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, kSmemSimple) != hipSuccess)
       return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   if (bwd) hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(256), kSmemSimple, s, p);
   else hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(256), kSmemSimple, s, p);
@@ -740,12 +740,12 @@ extern "C" int cmb_sva_abs_fwd(const cmb_sva_abs_desc* d, void* stream) {
   if (d->dtype == CMB_F32) return launch_simple<float>(p, false, (hipStream_t)stream);
   if (cmb_knob(CMB_KNOB_SVA_ABS) == 1) return launch_simple<bf16_t>(p, false, (hipStream_t)stream);
   const int64_t blocks = nq < (1 << 20) ? nq : (1 << 20);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sva_abs_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kSmemFwd) != hipSuccess)
       return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   hipLaunchKernelGGL(sva_abs_fwd_kernel, dim3((unsigned)blocks), dim3(64), kSmemFwd, (hipStream_t)stream, p);
   CMB_CHECK_LAUNCH();
@@ -761,12 +761,12 @@ extern "C" int cmb_sva_abs_bwd(const cmb_sva_abs_desc* d, void* stream) {
   if (d->dtype == CMB_F32) return launch_simple<float>(p, true, (hipStream_t)stream);
   if (cmb_knob(CMB_KNOB_SVA_ABS) == 1) return launch_simple<bf16_t>(p, true, (hipStream_t)stream);
   const int64_t blocks = nq < (1 << 20) ? nq : (1 << 20);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CmbAttrOnce attr_once;
+  if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sva_abs_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kSmemBwd) != hipSuccess)
       return CMB_ERR_LAUNCH;
-    attr_done = true;
+    attr_once.done(attr_bit);
   }
   hipLaunchKernelGGL(sva_abs_bwd_kernel, dim3((unsigned)blocks), dim3(64), kSmemBwd, (hipStream_t)stream, p);
   CMB_CHECK_LAUNCH();

@@ -539,12 +539,12 @@ extern "C" int cmb_vit_attn_fwd(int dtype, const void* qkv, int64_t B, int64_t N
 #define VIT_DMA_LAUNCH(HD_, NW_, WPE_, SMEM_)                                                                                  \
   do {                                                                                                                         \
     auto kern = vit_attn_dma_kernel<HD_, NW_, WPE_>;                                                                           \
-    static bool attr_done = false; /* up to 64 KiB of dynamic LDS: above the 48 KiB a kernel gets without asking */           \
-    if (!attr_done) {                                                                                                          \
+    static CmbAttrOnce attr_once; /* up to 64 KiB of dynamic LDS: above the 48 KiB a kernel gets without asking */           \
+    if (const uint32_t attr_bit = attr_once.need()) {                                                                                                          \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_) !=       \
           hipSuccess)                                                                                                          \
         return CMB_ERR_LAUNCH;                                                                                                 \
-      attr_done = true;                                                                                                        \
+      attr_once.done(attr_bit);                                                                                                        \
     }                                                                                                                          \
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * NW_), SMEM_, s, (const bf16_t*)qkv, (int)N, heads, nqb, sl2,     \
                        (bf16_t*)out);                                                                                          \
