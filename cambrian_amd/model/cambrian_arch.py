@@ -317,14 +317,13 @@ class CambrianMetaForCausalLM(ABC):
                         outs[i] = towers[i](image_aux_list[i])
                         outs[i].record_stream(main)   # allocated from st's pool, consumed on the main stream
             used.append(st)
-        for i, k in enumerate(plan):                  # ... then the towers that stay on the launch stream
-            if k == "0":
-                outs[i] = towers[i](image_aux_list[i])
+        # ... then the towers that stay on the launch stream (the two ViT trunks that pair best among them in lock-step)
+        self._encode_images_one_stream(image_aux_list, towers, frozen, only=[i for i, k in enumerate(plan) if k == "0"], outs=outs)
         for st in used:
             main.wait_stream(st)
         return outs
 
-    def _encode_images_one_stream(self, image_aux_list, towers, frozen):
+    def _encode_images_one_stream(self, image_aux_list, towers, frozen, only=None, outs=None):
         """Every tower on the launch stream.  Round 6: the two frozen ViT trunks whose blocks gain most from running side by
         side (DINOv2 and SigLIP at the release sizes: 1.62- and 1.35-round linears) advance in lock-step and hand their
         same-position residual linears to cmb_gemm_pair — one launch with the workgroups split between the two problems
@@ -335,7 +334,7 @@ class CambrianMetaForCausalLM(ABC):
         if (_PAIR_TOWERS and frozen and image_aux_list[0].is_cuda and not isinstance(image_aux_list[0], list)
                 and image_aux_list[0].dtype == torch.bfloat16):
             cand = [i for i, t in enumerate(towers)
-                    if isinstance(getattr(t, "vision_tower", None), ViTTrunk) and "trunk_out" in t._forward.__code__.co_varnames
+                    if (only is None or i in only) and isinstance(getattr(t, "vision_tower", None), ViTTrunk) and "trunk_out" in t._forward.__code__.co_varnames
                     and not isinstance(image_aux_list[i], list) and not t.vision_tower._ln_fused]
             best = 0.0
             for x in range(len(cand)):
@@ -344,8 +343,10 @@ class CambrianMetaForCausalLM(ABC):
                     gain = _pair_rounds_gain(towers[i].vision_tower, towers[j].vision_tower, image_aux_list[i].shape[0])
                     if gain > best:
                         best, pair = gain, (i, j)
-        outs = [None] * len(towers)
+        outs = [None] * len(towers) if outs is None else outs
         for k, (image_aux, tower) in enumerate(zip(image_aux_list, towers)):
+            if only is not None and k not in only:
+                continue
             if pair is not None and k == pair[1]:
                 continue                                  # produced together with pair[0]
             if pair is not None and k == pair[0]:
