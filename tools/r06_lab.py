@@ -258,3 +258,11 @@ if "contract" in verbs:   # the per-head N = 64 "contract" product of the absorb
     us = time_variants({"k": f}, iters=20)["k"]
     emit(case="contract", shape=f"{Bq}x{heads}x{hd} K={Cin}", kernel=L.load().cmb_gemm_last_kernel(), us=round(us, 1),
          read_tbps=round(xb.numel() * 2 / us / 1e6, 2), rel_err=err)
+
+if "plain" in verbs:   # plain (no epilogue work) launches of the persistent kernel on long-K and short-K shapes: the K loop's rate
+    for name, M, N, K in (("s3 fc1", B * 4096, 6144, 1536), ("s1 fc1", B * 65536, 1536, 384), ("s2 fc1", B * 16384, 3072, 768), ("8192^3/8", 8192, 8192, 4096)):
+        a, w = rn(M, K), rn(N, K, scale=K ** -0.5)
+        out = torch.empty(M, N, device=dev, dtype=bf)
+        us = time_variants({"p5": lambda: ops.k_gemm(a, w, out=out, tile=2590)}, iters=8)["p5"]
+        emit(case="plain", shape=f"{name} {M}x{N}x{K}", us=round(us, 1), tflops=round(2.0 * M * N * K / us / 1e6))
+        del a, w, out
