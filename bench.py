@@ -936,6 +936,9 @@ def main():
                        "peak_hbm_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
                        "peak_hbm_reserved_gb": torch.cuda.max_memory_reserved() / 2 ** 30},
         }
+        from cambrian_amd.model import cambrian_arch as _arch
+        line["config"]["tower_pairing"] = ("two frozen ViT trunks in lock-step, same-position residual linears through cmb_gemm_pair "
+                                           "(one launch, workgroups split between the problems)") if _arch._PAIR_TOWERS else "off"
         if batch_fallback:
             line["config"]["batch_fallback"] = batch_fallback
         if args.scored_rows:
