@@ -29,10 +29,16 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4_t* lds_tr_ptr;
 
-constexpr int BM = 128, BN = 128, BKR = 64;                // BKR: rows (k) per stage
-constexpr int OP_BYTES = BKR * 256, STAGE = 2 * OP_BYTES;  // 16 KiB per operand, 32 KiB per stage
+// Round 6: a ring of FOUR 32-row stages instead of two 64-row ones (the same 64 KiB).  With two stages every K-step ended in
+// s_waitcnt vmcnt(0) + barrier, so a stage's DMA had ONE step of MFMAs (16 per wave, ~0.25 us) to land in: the split-K weight
+// gradients of the SVA layers ran 1.4-1.5 us per 64 rows — the round trip to HBM, not the arithmetic (2048 x 1024 x 13 824:
+// 79 us for 58 GFLOP).  Now stage t + 3 is requested while stage t is consumed, the wait is counted (the two younger stages
+// stay in flight) and a step has one raw barrier.
+constexpr int BM = 128, BN = 128, BKR = 32;                // BKR: rows (k) per stage
+constexpr int NST = 4;                                     // stages in the ring
+constexpr int OP_BYTES = BKR * 256, STAGE = 2 * OP_BYTES;  // 8 KiB per operand, 16 KiB per stage
 constexpr int CS = BN + 4;
-constexpr int SMEM = (2 * STAGE) > (BM * CS * 4) ? (2 * STAGE) : (BM * CS * 4);
+constexpr int SMEM = (NST * STAGE) > (BM * CS * 4) ? (NST * STAGE) : (BM * CS * 4);
 
 __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,30 +64,36 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
   const int nk = (kend > kbeg) ? (kend - kbeg + BKR - 1) / BKR : 0;
   const int64_t lda = p.a_map.s2, ldb = p.ldb;
 
-  // ---- LDS-DMA sources.  An operand stage is 16 pieces of 1 KiB (4 rows each); wave w issues pieces w, w + 4, w + 8,
-  // w + 12 of At and of Bt.  Lane l of a piece: row l >> 4, LDS slot l & 15 <- source slot (l & 15) ^ 4 (l >> 4).
+  // ---- LDS-DMA sources.  An operand stage is 8 pieces of 1 KiB (4 rows each); wave w issues pieces w and w + 4 of At and of
+  // Bt.  Lane l of a piece: row l >> 4, LDS slot l & 15 <- source slot (l & 15) ^ 4 (l >> 4).
   // Columns beyond M / N (whole 8-column slots: M, N are multiples of 8) re-read the tile's first slot; never stored.
   const int sx = lane & 15;
   const int sc = tn_dma_src_slot(lane);
   const int acol = (m0 + sc * 8 < p.M) ? (m0 + sc * 8) : m0;
   const int bcol = (n0 + sc * 8 < p.N) ? (n0 + sc * 8) : n0;
   const char* zsrc = g_zero_row + sx * 16;
-  const char* a_src[4];
-  const char* b_src[4];
-  int krow[4];
+  const char* a_src[2];
+  const char* b_src[2];
+  int krow[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 2; ++i) {
     krow[i] = kbeg + tn_dma_row(wave + 4 * i, lane);
     a_src[i] = p.A + ((int64_t)krow[i] * lda + acol) * 2;
     b_src[i] = p.B + ((int64_t)krow[i] * ldb + bcol) * 2;
   }
-  auto stage = [&](int s) {
-    char* sa = smem + s * STAGE;
+  // The DMA is inline asm (M0 + the load in one statement): through the builtin hipcc knows the instruction writes LDS and
+  // parks s_waitcnt vmcnt(0) in front of the first fragment read of every step — the ring would drain each step.
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem));
+  auto dma = [&](const char* g, uint32_t lds_byte) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_byte) : "memory", "m0");
+  };
+  auto stage = [&](int s) {   // 4 LDS-DMA instructions per wave
+    const uint32_t sa = lds0 + (uint32_t)(s * STAGE);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       const bool live = krow[i] < kend;
-      glds16(live ? a_src[i] : zsrc, sa + tn_dma_lds_off(wave + 4 * i, 0));
-      glds16(live ? b_src[i] : zsrc, sa + OP_BYTES + tn_dma_lds_off(wave + 4 * i, 0));
+      dma(live ? a_src[i] : zsrc, sa + (uint32_t)tn_dma_lds_off(wave + 4 * i, 0));
+      dma(live ? b_src[i] : zsrc, sa + (uint32_t)(OP_BYTES + tn_dma_lds_off(wave + 4 * i, 0)));
       a_src[i] += (int64_t)BKR * lda * 2;
       b_src[i] += (int64_t)BKR * ldb * 2;
       krow[i] += BKR;
@@ -108,15 +120,22 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   if (nk > 0) {
+    // prologue: stages 0, 1, 2 requested; step t: wait for stage t (the younger ones stay in flight), barrier (every wave's
+    // pieces of stage t have landed AND every wave is done reading stage t - 1), request stage t + 3 into the buffer stage
+    // t - 1 used, consume stage t.  Raw s_barrier: __syncthreads() would drain the LDS-DMA queue (vmcnt(0)) every step.
     stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (nk > 1) stage(1);
+    if (nk > 2) stage(2);
     for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) stage(cur ^ 1);  // async: lands while this K-step's MFMAs run
-      const char* base = smem + cur * STAGE;
+      const int ahead = nk - 1 - kt;   // stages requested behind stage kt (capped at 2)
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      if (kt + 3 < nk) stage((kt + 3) & (NST - 1));
+      const char* base = smem + (kt & (NST - 1)) * STAGE;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < 2; ++s) {
         bf16x8_t a[2], b[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -135,9 +154,9 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(const GemmParams p_in) {
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);  // swapped: rows = n, cols = m
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");   // every wave is done with the operand ring: the epilogue reuses it
   }
 
   // ---- epilogue: accumulators -> LDS (fp32, row stride BN + 4) -> row-contiguous global stores (as gemm.hip)
