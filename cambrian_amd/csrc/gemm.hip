@@ -620,7 +620,7 @@ extern "C" int cmb_gemm_pair(const cmb_gemm_desc* d0, const cmb_gemm_desc* d1, v
   };
   static int debug = -1;
   if (debug < 0) debug = getenv("CMB_GEMM_PAIR_DEBUG") ? 1 : 0;
-  if (enabled && simple(d0) && simple(d1) && d0->act == d1->act) {
+  if (enabled && simple(d0) && simple(d1) && d0->act == d1->act && gemm_p5_pair_act_ok(d0->act)) {
     GemmParams p0, p1;
     int s0 = 1, s1 = 1;
     const int r0 = gemm_params_from_desc<bf16_t>(d0, p0, s0), r1 = gemm_params_from_desc<bf16_t>(d1, p1, s1);

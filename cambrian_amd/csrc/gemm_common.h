@@ -188,6 +188,7 @@ int launch_gemm256_bf16(GemmParams& p, int splits, int sched, hipStream_t s);
 // q != nullptr: a pair launch — q (same activation, whole K, no slabs) runs beside p on its own share of the workgroups
 int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s, GemmParams* q = nullptr);
 double gemm_p5_pair_gain(const GemmParams& a, const GemmParams& b, int n_cu);
+bool gemm_p5_pair_act_ok(int act);   // activation templates that have a pair instantiation
 
 // gemm_k64.hip: batched problems with a 64-deep contraction and a wide N (the per-head expand products): HBM-write-bound kernel
 bool gemm_k64_eligible(const GemmParams& p);

@@ -209,11 +209,17 @@ struct P5Src {
 // DINOv2's and SigLIP's linears at 24 images are 414 / 345 tiles: 1.62 / 1.35 rounds of 256 workgroups, i.e. two rounds each
 // for 2.97 rounds of work; side by side on 138 + 118 workgroups they are 3.0 + 2.9 rounds (gemm.hip: cmb_gemm_pair picks g0).
 // A workgroup picks its problem ONCE: everything below reads `p` through one reference as before.
+}  // namespace
 struct P5Args {
   GemmParams prob[2];
   int n_items[2];
   int g0;   // workgroups of problem 0 (single launches: the whole grid)
 };
+// gemm_p5_pair.hip (this file compiled with CMB_P5_PAIR_TU: the PAIR = true instantiations are their own translation unit, so the
+// two halves of the ~3 minutes of hipcc run side by side under make -j)
+int p5_pair_set_attr(int smem);
+int p5_pair_launch(int act, unsigned grid, int smem, hipStream_t s, const P5Args& args);
+namespace {
 
 // PAIR = false is the single launch: problem 0 at fixed kernel-argument offsets, exactly the code of rounds 2-5.  (One
 // instantiation for both, `p` chosen at run time, made every single launch 1-5 % slower — the parameter block is then read with
@@ -406,6 +412,7 @@ __global__ void __launch_bounds__(256) gemm_nt_p5_kernel(const P5Args args) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
+#ifndef CMB_P5_PAIR_TU
 // Workgroups of problem 0 in a pair launch: the split g0 in [1, n_cu) that minimises max over the two sides of
 // rounds x (K tiles per item + epilogue), rounds = ceil(items / workgroups) (whole XCD multiples are not needed: a side's items
 // are numbered from its own first workgroup).
@@ -438,12 +445,15 @@ int launch_p5_act(GemmParams& p, int splits, hipStream_t s, GemmParams* q = null
   constexpr int smem = 2 * kP5Buf + 4 * 8192;  // two operand buffers + the epilogue's staging area = all 160 KiB
   static CmbAttrOnce attr_once;
   static int n_cu = 0;
+  // pair launches exist for the plain and the erf-GELU epilogue templates only (the residual linears of the ViT blocks are
+  // plain; every further instantiation is 35 s of compile time): gemm_p5_pair_act_ok() tells cmb_gemm_pair
+  constexpr bool kPairAct = ACT == CMB_ACT_NONE || ACT == CMB_ACT_GELU_ERF;
   auto kern = gemm_nt_p5_kernel<ACT, false>;
-  auto kern2 = gemm_nt_p5_kernel<ACT, true>;
+  if (q && !kPairAct) return CMB_ERR_BAD_ARG;
   if (const uint32_t attr_bit = attr_once.need()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
             hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        p5_pair_set_attr(smem) != CMB_OK)
       return CMB_ERR_LAUNCH;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -477,8 +487,8 @@ int launch_p5_act(GemmParams& p, int splits, hipStream_t s, GemmParams* q = null
     args.n_items[1] = 0;
   }
   args.g0 = g0;
-  if (q) hipLaunchKernelGGL(kern2, dim3((unsigned)grid), dim3(256), smem, s, args);
-  else hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, args);
+  if (q) return p5_pair_launch(ACT, (unsigned)grid, smem, s, args);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, args);
   CMB_CHECK_LAUNCH();
   return CMB_OK;
 }
@@ -496,11 +506,34 @@ int launch_gemm_p5_bf16(GemmParams& p, int splits, hipStream_t s, GemmParams* q)
   }
 }
 
+bool gemm_p5_pair_act_ok(int act) { return act == CMB_ACT_NONE || act == CMB_ACT_GELU_ERF; }
+
 // cost model of a pair launch against the two single launches (K tiles + epilogue per item, whole rounds): > 0 = the pair wins
 double gemm_p5_pair_gain(const GemmParams& a, const GemmParams& b, int n_cu) {
   const int ia = ((a.M + 255) / 256) * ((a.N + 255) / 256), ib = ((b.M + 255) / 256) * ((b.N + 255) / 256);
   const double single = p5_pair_cost(ia, a.K, ib, b.K, n_cu, false), pair = p5_pair_cost(ia, a.K, ib, b.K, n_cu, true);
   return (single - pair) / single;
 }
+
+#else   // CMB_P5_PAIR_TU: only the pair instantiations and their two entry points
+}  // namespace
+
+int p5_pair_set_attr(int smem) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_p5_kernel<CMB_ACT_NONE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          smem) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_p5_kernel<CMB_ACT_GELU_ERF, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          smem) != hipSuccess)
+    return CMB_ERR_LAUNCH;
+  return CMB_OK;
+}
+
+int p5_pair_launch(int act, unsigned grid, int smem, hipStream_t s, const P5Args& args) {
+  if (act == CMB_ACT_GELU_ERF) hipLaunchKernelGGL((gemm_nt_p5_kernel<CMB_ACT_GELU_ERF, true>), dim3(grid), dim3(256), smem, s, args);
+  else if (act == CMB_ACT_NONE) hipLaunchKernelGGL((gemm_nt_p5_kernel<CMB_ACT_NONE, true>), dim3(grid), dim3(256), smem, s, args);
+  else return CMB_ERR_BAD_ARG;
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
+}
+#endif
 
 }  // namespace cmb_gemm_detail
