@@ -477,10 +477,23 @@ extern "C" int cmb_weight_prep(const cmb_prep_job* jobs_device, int32_t n_jobs, 
   return CMB_OK;
 }
 
+// rows per workgroup of the column sums: 256 for the tall inputs (221 184 rows), fewer when that would leave most of the chip
+// idle — the SVA query-side inputs are 13 824 x 1024: 108 workgroups of 256 rows ran 27-60 us for 28 MB.  The launch aims at
+// CMB_KNOB_COLSUM_WGS workgroups (one atomicAdd per column and workgroup either way; 0 = always 256 rows, rounds 1-5)
+static int colsum_rows_per_block(int64_t R, int64_t C) {
+  const int target = cmb_knob(CMB_KNOB_COLSUM_WGS);
+  if (target <= 0) return 256;
+  const int64_t col_groups = (C + 511) / 512;
+  int64_t rpb = (R * col_groups / target + 3) & ~(int64_t)3;
+  if (rpb < 16) rpb = 16;
+  if (rpb > 256) rpb = 256;
+  return (int)rpb;
+}
+
 extern "C" int cmb_colsum(int dtype, const void* in, int64_t R, int64_t C, int64_t ld_in, float* out, void* stream) {
   if (!in || !out || R < 0 || C <= 0 || (C & 7) || (ld_in & 7)) return CMB_ERR_BAD_ARG;
   if (R == 0) return CMB_OK;
-  const int rows_per_block = 256;
+  const int rows_per_block = colsum_rows_per_block(R, C);
   dim3 grid((unsigned)((C + 511) / 512), (unsigned)((R + rows_per_block - 1) / rows_per_block));
   DT_SWITCH(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C,
                                       ld_in, out, rows_per_block));
@@ -492,7 +505,7 @@ extern "C" int cmb_colsum_scaled(int dtype, const void* in, int64_t R, int64_t C
                                  int64_t ld_scale, int32_t group, float* out, void* stream) {
   if (!in || !out || !row_scale || R < 0 || C <= 0 || (C & 7) || group <= 0 || (group & 7) || C % group) return CMB_ERR_BAD_ARG;
   if (R == 0) return CMB_OK;
-  const int rows_per_block = 256;
+  const int rows_per_block = colsum_rows_per_block(R, C);
   dim3 grid((unsigned)((C + 511) / 512), (unsigned)((R + rows_per_block - 1) / rows_per_block));
   DT_SWITCH(dtype, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)in, R, C, ld_in, out,
                                       rows_per_block, row_scale, ld_scale, (int)group));
@@ -668,6 +681,8 @@ extern "C" int cmb_knob_set(int32_t knob, int32_t value) {
     case CMB_KNOB_VIT_ATTN: ok = value >= 0 && value <= 3; break;              // 2 = LDS-DMA tiles + transposing reads (round 6)
     case CMB_KNOB_SVA_ABS: ok = value == 0 || value == 1; break;
     case CMB_KNOB_LN_MULTI_CHUNK: ok = value == 4 || value == 7; break;
+    case CMB_KNOB_COLSUM_WGS: ok = value >= 0 && value <= 65536; break;        // 0 = 256 rows per workgroup / workgroup target
+    case CMB_KNOB_LN_BWD_ROWS: ok = value >= 4 && value <= 256; break;
     case CMB_KNOB_FLASH: ok = value >= 0 && value <= 31 && !(value & 8); break;   // bit mask: 1 forward, 2 dQ, 4 dK/dV body, 16 dK/dV transposing reads (8: removed)
     default: ok = value >= 0; break;
   }

@@ -878,7 +878,8 @@ int ln_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t row
   int64_t blocks = (nwin + 63) / 64;  // ~16 rows per wave: amortises the end-of-block atomics
   // ... unless that leaves the chip mostly idle (the SVA query-side LayerNorms: 13 824 rows = 216 workgroups, 61 us = 0.16 of
   // the HBM peak, profiles/r03_hbm_kernels_table.md): then ~4 rows per wave
-  if (blocks < 1024) blocks = (nwin + 15) / 16;
+  // (CMB_KNOB_LN_BWD_ROWS rows per workgroup: every workgroup ends with one atomicAdd per column and parameter)
+  if (blocks < 1024) blocks = (nwin + cmb_knob(CMB_KNOB_LN_BWD_ROWS) - 1) / cmb_knob(CMB_KNOB_LN_BWD_ROWS);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   const size_t smem = (size_t)4 * D * sizeof(float);

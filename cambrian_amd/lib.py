@@ -24,7 +24,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "gelu_tanh": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
-KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS, KNOB_LN_MULTI_CHUNK, KNOB_FLASH = 0, 1, 2, 3, 4, 5   # enum cmb_knob_id
+KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS, KNOB_LN_MULTI_CHUNK, KNOB_FLASH, KNOB_COLSUM_WGS, KNOB_LN_BWD_ROWS = 0, 1, 2, 3, 4, 5, 6, 7   # enum cmb_knob_id
 ABI_VERSION = 8   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",

@@ -90,10 +90,15 @@ int cmb_abi_version(void);
  *                       Q^T / dO^T fragments with transposing reads from swizzled row-major images (no transposed copies); 0 = the
  *                       round-4 kernels.  Default 23.  (Bit 8 selected a dK/dV kernel on LDS-DMA tiles that measured slower —
  *                       profiles/r05_lab.md — and was removed in round 6: values with it are rejected.)  dQ / dK / dV are
- *                       bit-identical across variants, the forward to fp32 rounding (tests/test_flash_bwd_gpu.py) */
+ *                       bit-identical across variants, the forward to fp32 rounding (tests/test_flash_bwd_gpu.py)
+ *   CMB_KNOB_COLSUM_WGS cmb_colsum / cmb_colsum_scaled: 0 = 256 rows per workgroup whatever the input (rounds 1-5); n > 0 = rows per
+ *                       workgroup chosen so that the launch has about n workgroups (16 ... 256 rows; same sums up to the order of
+ *                       the fp32 atomics, which was never fixed; default 768: 13 824 x 1024 24 -> 14 us, scaled 42 -> 17 us)
+ *   CMB_KNOB_LN_BWD_ROWS cmb_layernorm_bwd on inputs of < 65 536 rows per window position: rows per workgroup (4 ... 256; 16 = rounds
+ *                       3-5, default 32: 13 824 x 1024 51 -> 39 us) — fewer workgroups = fewer end-of-block atomics on the parameter gradients, more = more rows in flight */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
-                   CMB_KNOB_FLASH = 5, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 1, 1, 2, 0, 4, 23, 0, 0
+                   CMB_KNOB_FLASH = 5, CMB_KNOB_COLSUM_WGS = 6, CMB_KNOB_LN_BWD_ROWS = 7, CMB_KNOB_COUNT = 8 };
+#define CMB_KNOB_DEFAULTS 1, 1, 2, 0, 4, 23, 768, 32
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 

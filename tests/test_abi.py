@@ -108,7 +108,7 @@ def test_knob_values_are_validated(built):
     grid or silently select another variant."""
     lib = built.load()
     ok, bad = 0, -1
-    saved = [lib.cmb_knob_get(k) for k in range(5)]
+    saved = [lib.cmb_knob_get(k) for k in range(8)]
     try:
         assert lib.cmb_knob_set(built.KNOB_DWCONV, -3) == bad
         assert lib.cmb_knob_set(built.KNOB_LN_FWD, -1) == bad
@@ -116,7 +116,10 @@ def test_knob_values_are_validated(built):
         assert lib.cmb_knob_set(built.KNOB_SVA_ABS, 7) == bad
         assert lib.cmb_knob_set(built.KNOB_LN_MULTI_CHUNK, 5) == bad
         assert lib.cmb_knob_set(99, 0) == bad
-        assert [lib.cmb_knob_get(k) for k in range(5)] == saved          # a rejected value changes nothing
+        assert lib.cmb_knob_set(built.KNOB_COLSUM_WGS, -1) == bad
+        assert lib.cmb_knob_set(built.KNOB_LN_BWD_ROWS, 0) == bad and lib.cmb_knob_set(built.KNOB_LN_BWD_ROWS, 257) == bad
+        assert [lib.cmb_knob_get(k) for k in range(8)] == saved          # a rejected value changes nothing
+        assert lib.cmb_knob_set(built.KNOB_COLSUM_WGS, 0) == ok and lib.cmb_knob_set(built.KNOB_LN_BWD_ROWS, 64) == ok
         assert lib.cmb_knob_set(built.KNOB_LN_MULTI_CHUNK, 7) == ok and lib.cmb_knob_get(built.KNOB_LN_MULTI_CHUNK) == 7
         assert lib.cmb_knob_set(built.KNOB_DWCONV, 32) == ok
     finally:

@@ -674,3 +674,54 @@ def test_colsum_scaled_matches_broadcast_product(dev):
         got = ops.k_colsum(x, row_scale=sc, group=64)
         want = (sc.double()[:, :, None] * x.double().view(R, 16, 64)).sum(0).reshape(1024)
         assert ((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-6)).item() < 1e-5
+
+
+@pytest.mark.parametrize("wgs", [0, 64, 512, 4096])
+def test_colsum_workgroup_targets(dev, wgs):
+    """CMB_KNOB_COLSUM_WGS only changes how the rows are cut into workgroups: ragged row counts, column counts that are not a
+    multiple of 512, strided inputs, plain and scaled sums against fp64."""
+    import torch
+    from cambrian_amd import lib as L, ops
+    g = torch.Generator().manual_seed(11)
+    saved = L.knob_get(L.KNOB_COLSUM_WGS)
+    try:
+        L.knob_set(L.KNOB_COLSUM_WGS, wgs)
+        for R, C_ in ((1, 64), (19, 1032), (13824, 1024), (5000, 2048)):
+            wide = torch.randn(R, C_ + 64, generator=g).to(dev, torch.bfloat16)
+            x = wide[:, :C_]                                   # row stride C + 64
+            want = x.double().sum(0)
+            got = ops.k_colsum(x)
+            assert ((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-6)).item() < 2e-5
+            if C_ % 64 == 0:
+                sc = torch.randn(R, C_ // 64, generator=g).to(dev)
+                want = (sc.double()[:, :, None] * x.double().reshape(R, C_ // 64, 64)).sum(0).reshape(C_)
+                got = ops.k_colsum(x, row_scale=sc, group=64)
+                assert ((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-6)).item() < 2e-5
+    finally:
+        L.knob_set(L.KNOB_COLSUM_WGS, saved)
+
+
+@pytest.mark.parametrize("rpb", [4, 16, 64, 256])
+def test_layernorm_bwd_rows_per_workgroup(dev, rpb):
+    """CMB_KNOB_LN_BWD_ROWS: the same gradients whatever the number of rows a workgroup sums before its atomics."""
+    import torch
+    from cambrian_amd import lib as L, ops
+    g = torch.Generator().manual_seed(12)
+    rows, D = 1357, 1024
+    x = torch.randn(rows, D, generator=g).to(dev, torch.bfloat16)
+    dy = torch.randn(rows, D, generator=g).to(dev, torch.bfloat16)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    xr = x.float().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = torch.zeros(D, device=dev, requires_grad=True)
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5).backward(dy.float())
+    _, mean, rstd = ops.k_layernorm_fwd(x, gamma, torch.zeros(D, device=dev), 1e-5)
+    saved = L.knob_get(L.KNOB_LN_BWD_ROWS)
+    try:
+        L.knob_set(L.KNOB_LN_BWD_ROWS, rpb)
+        dx, dgamma, dbeta, _ = ops.k_layernorm_bwd(dy, x, mean, rstd, gamma=gamma)
+    finally:
+        L.knob_set(L.KNOB_LN_BWD_ROWS, saved)
+    assert rel_err(dx.float().cpu(), xr.grad.cpu()) < 2e-2
+    assert rel_err(dgamma.cpu(), gr.grad.cpu()) < 1e-4
+    assert rel_err(dbeta.cpu(), br.grad.cpu()) < 1e-4

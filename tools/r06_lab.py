@@ -266,3 +266,41 @@ if "plain" in verbs:   # plain (no epilogue work) launches of the persistent ker
         us = time_variants({"p5": lambda: ops.k_gemm(a, w, out=out, tile=2590)}, iters=8)["p5"]
         emit(case="plain", shape=f"{name} {M}x{N}x{K}", us=round(us, 1), tflops=round(2.0 * M * N * K / us / 1e6))
         del a, w, out
+
+if "colsum" in verbs:   # column sums at the step's shapes: knob COLSUM_WGS 0 (256 rows per workgroup) against workgroup targets
+    for (R, Cc, scaled) in ((B * 576, 1024, False), (B * 576, 2048, False), (B * 576, 4096, False), (B * 576, 1024, True),
+                            (B * 9216, 2048, False)):
+        x = rn(R, Cc)
+        sc = rn(R, Cc // 64, dtype=f32) if scaled else None
+        out = torch.zeros(Cc, device=dev)
+        ref = x.float().mul(sc.repeat_interleave(64, 1)).sum(0) if scaled else x.float().sum(0)
+        fns, errs = {}, {}
+        for wgs in (0, 256, 512, 1024, 2048):
+            def f(wgs=wgs):
+                L.knob_set(L.KNOB_COLSUM_WGS, wgs)
+                ops.k_colsum(x, out, row_scale=sc, group=64 if scaled else 0)
+            out.zero_()
+            f()
+            errs[str(wgs)] = float((out - ref).abs().max() / ref.abs().max())
+            fns[str(wgs)] = f
+        us = time_variants(fns)
+        emit(case="colsum", R=R, C=Cc, scaled=scaled, us={k: round(v, 1) for k, v in us.items()}, rel_err=errs)
+    L.knob_set(L.KNOB_COLSUM_WGS, 768)
+
+if "lnbwd" in verbs:   # LayerNorm backward of the SVA query-side inputs (13 824 x 1024, affine): rows per workgroup
+    rows, D = B * 576, 1024
+    x, dy, gamma = rn(rows, D), rn(rows, D), rn(D, dtype=f32)
+    _, mean, rstd = ops.k_layernorm_fwd(x, gamma, torch.zeros(D, device=dev), 1e-5)
+    fns, ref, errs = {}, None, {}
+    for rpb in (8, 16, 32, 64, 128):
+        def f(rpb=rpb):
+            L.knob_set(L.KNOB_LN_BWD_ROWS, rpb)
+            return ops.k_layernorm_bwd(dy, x, mean, rstd, gamma=gamma)
+        got = f()
+        if ref is None:
+            ref = got
+        errs[str(rpb)] = [float((g.float() - r_.float()).abs().max() / r_.float().abs().max()) for g, r_ in zip(got[:3], ref[:3])]
+        fns[str(rpb)] = f
+    us = time_variants(fns)
+    emit(case="lnbwd", rows=rows, D=D, us={k: round(v, 1) for k, v in us.items()}, rel_diff_vs_8=errs)
+    L.knob_set(L.KNOB_LN_BWD_ROWS, 32)
