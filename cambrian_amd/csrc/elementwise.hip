@@ -680,7 +680,7 @@ extern "C" int cmb_knob_set(int32_t knob, int32_t value) {
     case CMB_KNOB_DWCONV: ok = value >= 0 && value <= 4096; break;            // 0 / 1 / rows per chunk
     case CMB_KNOB_VIT_ATTN: ok = value >= 0 && value <= 3; break;              // 2 = LDS-DMA tiles + transposing reads (round 6)
     case CMB_KNOB_SVA_ABS: ok = value == 0 || value == 1; break;
-    case CMB_KNOB_LN_MULTI_CHUNK: ok = value == 4 || value == 7; break;
+    case CMB_KNOB_LN_MULTI_CHUNK: ok = value >= 4 && value <= 7; break;
     case CMB_KNOB_COLSUM_WGS: ok = value >= 0 && value <= 65536; break;        // 0 = 256 rows per workgroup / workgroup target
     case CMB_KNOB_LN_BWD_ROWS: ok = value >= 4 && value <= 256; break;
     case CMB_KNOB_FLASH: ok = value >= 0 && value <= 31 && !(value & 8); break;   // bit mask: 1 forward, 2 dQ, 4 dK/dV body, 16 dK/dV transposing reads (8: removed)

@@ -424,7 +424,8 @@ struct LnMultiParams {
 };
 
 template <typename T, int NCH, bool ACCUM, int LC>
-__global__ void __launch_bounds__(256) layernorm_bwd_multi_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int D,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LC <= 5 ? 2 : 1)))
+layernorm_bwd_multi_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int D,
                                                                   int side, int grid_r, const LnMultiParams mp,
                                                                   float* __restrict__ dx, int64_t lddx) {
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
@@ -992,7 +993,8 @@ extern "C" int cmb_layernorm_bwd_multi(const cmb_ln_multi_desc* d, void* stream)
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipStream_t s = (hipStream_t)stream;
-  const int kChunk = cmb_knob(CMB_KNOB_LN_MULTI_CHUNK) == 4 ? 4 : 7;   // layers per launch (4: two waves per SIMD)
+  int kChunk = cmb_knob(CMB_KNOB_LN_MULTI_CHUNK);   // layers per launch (4 ... 7; <= 6: two waves per SIMD)
+  if (kChunk < 4 || kChunk > 7) kChunk = 4;
   for (int l0 = 0; l0 < d->layers; l0 += kChunk) {
     LnMultiParams mp;
     mp.layers = d->layers - l0 < kChunk ? d->layers - l0 : kChunk;
@@ -1010,7 +1012,9 @@ extern "C" int cmb_layernorm_bwd_multi(const cmb_ln_multi_desc* d, void* stream)
                      (const T_*)d->x, d->ldx, d->rows, (int)d->D, side, grid_r, mp, d->dx, d->lddx)
 #define LN_MULTI_T(T_)                                                                      \
   do {                                                                                      \
-    if (mp.layers > 4) { if (acc) LN_MULTI_LAUNCH(T_, true, 7); else LN_MULTI_LAUNCH(T_, false, 7); } \
+    if (mp.layers > 6) { if (acc) LN_MULTI_LAUNCH(T_, true, 7); else LN_MULTI_LAUNCH(T_, false, 7); } \
+    else if (mp.layers > 5) { if (acc) LN_MULTI_LAUNCH(T_, true, 6); else LN_MULTI_LAUNCH(T_, false, 6); } \
+    else if (mp.layers > 4) { if (acc) LN_MULTI_LAUNCH(T_, true, 5); else LN_MULTI_LAUNCH(T_, false, 5); } \
     else if (mp.layers > 2) { if (acc) LN_MULTI_LAUNCH(T_, true, 4); else LN_MULTI_LAUNCH(T_, false, 4); } \
     else { if (acc) LN_MULTI_LAUNCH(T_, true, 2); else LN_MULTI_LAUNCH(T_, false, 2); }      \
   } while (0)

@@ -909,8 +909,9 @@ def layernorm(x, gamma, beta, eps: float = 1e-5):
 
 
 DEFER_LN_BWD = os.environ.get("CAMBRIAN_AMD_DEFER_LN_BWD", "1") != "0"   # (A/B runs: 0 = one LayerNorm backward per SVA layer)
-# parked layers per flush (= the 4-layer launches of cmb_layernorm_bwd_multi; 0 = only when the shared-gradient node runs)
-DEFER_LN_FLUSH = int(os.environ.get("CAMBRIAN_AMD_DEFER_LN_FLUSH", "4"))
+# parked layers per flush (= the 5-layer launches of cmb_layernorm_bwd_multi, CMB_KNOB_LN_MULTI_CHUNK; 0 = only when the
+# shared-gradient node runs)
+DEFER_LN_FLUSH = int(os.environ.get("CAMBRIAN_AMD_DEFER_LN_FLUSH", "5"))
 
 
 class GradAccumulator:
@@ -941,7 +942,7 @@ class GradAccumulator:
     def flush(self) -> None:
         """Run the parked LayerNorm backwards (one cmb_layernorm_bwd_multi call per window geometry) into the shared fp32
         buffer and release their gradient tensors.  Called by SvaNormFn.backward whenever DEFER_LN_FLUSH layers are parked
-        (= the kernel's 4-layer launches: same launches as one call at the end, but at most 4 layers' d(x-hat) — 1.8 GB at
+        (= the kernel's 5-layer launches: same launches as one call at the end, but at most 5 layers' d(x-hat) — 2.3 GB at
         24 images instead of 5.9 GB — are alive at a time) and by SharedGradFn.backward for the rest."""
         items, self.deferred = self.deferred, []
         if not items:

@@ -84,7 +84,8 @@ int cmb_abi_version(void);
  *                       same with 256 queries per workgroup (2 / 3 agree with 0 / 1 to bf16 rounding, not bit for bit)
  *   CMB_KNOB_SVA_ABS    cmb_sva_abs_fwd / _bwd on bf16 operands: 0 = the MFMA kernels; 1 = the exact (plain fp32 arithmetic)
  *                       instantiation of the same algorithm that dtype CMB_F32 always runs (tests: one against the other)
- *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 7 (one wave per SIMD) or 4 (two)
+ *   CMB_KNOB_LN_MULTI_CHUNK  cmb_layernorm_bwd_multi: layers per launch, 4 ... 7 (4, 5: two waves per SIMD; 6, 7: one).  13 layers of the
+ *                       9216-token tower at 24 images: 4: 4684 us, 5: 4463, 6: 6431, 7: 6455 (profiles/r06_lab.md)
  *   CMB_KNOB_FLASH      cmb_flash_attn_fwd / _bwd, bit mask: 1 = forward, 2 = dQ on LDS-DMA operand tiles with transposing reads
  *                       (flash2.hip); 4 = the round-4 dK/dV kernel with the round-5 four-phase tile body; 16 = that kernel reading its
  *                       Q^T / dO^T fragments with transposing reads from swizzled row-major images (no transposed copies); 0 = the
@@ -98,7 +99,7 @@ int cmb_abi_version(void);
  *                       3-5, default 32: 13 824 x 1024 51 -> 39 us) — fewer workgroups = fewer end-of-block atomics on the parameter gradients, more = more rows in flight */
 enum cmb_knob_id { CMB_KNOB_LN_FWD = 0, CMB_KNOB_DWCONV = 1, CMB_KNOB_VIT_ATTN = 2, CMB_KNOB_SVA_ABS = 3, CMB_KNOB_LN_MULTI_CHUNK = 4,
                    CMB_KNOB_FLASH = 5, CMB_KNOB_COLSUM_WGS = 6, CMB_KNOB_LN_BWD_ROWS = 7, CMB_KNOB_COUNT = 8 };
-#define CMB_KNOB_DEFAULTS 1, 1, 2, 0, 4, 23, 768, 32
+#define CMB_KNOB_DEFAULTS 1, 1, 2, 0, 5, 23, 768, 32
 int cmb_knob_set(int32_t knob, int32_t value);   /* CMB_ERR_BAD_ARG for an unknown knob */
 int cmb_knob_get(int32_t knob);                  /* -1 for an unknown knob */
 

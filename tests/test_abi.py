@@ -114,7 +114,7 @@ def test_knob_values_are_validated(built):
         assert lib.cmb_knob_set(built.KNOB_LN_FWD, -1) == bad
         assert lib.cmb_knob_set(built.KNOB_VIT_ATTN, 4) == bad
         assert lib.cmb_knob_set(built.KNOB_SVA_ABS, 7) == bad
-        assert lib.cmb_knob_set(built.KNOB_LN_MULTI_CHUNK, 5) == bad
+        assert lib.cmb_knob_set(built.KNOB_LN_MULTI_CHUNK, 3) == bad and lib.cmb_knob_set(built.KNOB_LN_MULTI_CHUNK, 8) == bad
         assert lib.cmb_knob_set(99, 0) == bad
         assert lib.cmb_knob_set(built.KNOB_COLSUM_WGS, -1) == bad
         assert lib.cmb_knob_set(built.KNOB_LN_BWD_ROWS, 0) == bad and lib.cmb_knob_set(built.KNOB_LN_BWD_ROWS, 257) == bad

@@ -617,7 +617,8 @@ def test_vit_attn_variants(dev, N, heads, hd):
 @pytest.mark.parametrize("name,dt", DTYPES)
 @pytest.mark.parametrize("L_,D,side,r,with_acc", [(13, 1024, 8, 4, True), (3, 1024, 6, 2, False), (17, 1024, 4, 1, False),
                                                     (5, 512, 8, 4, True), (2, 384, 4, 2, False)])
-def test_layernorm_bwd_multi_equals_layer_by_layer(dev, name, dt, L_, D, side, r, with_acc):
+@pytest.mark.parametrize("chunk", [4, 5, 6, 7])
+def test_layernorm_bwd_multi_equals_layer_by_layer(dev, name, dt, L_, D, side, r, with_acc, chunk):
     """cmb_layernorm_bwd_multi (one pass over x for all layers: the SVA layers' deferred LayerNorm backwards) against
     cmb_layernorm_bwd run layer by layer into the fp32 accumulator, and against autograd of F.layer_norm: d(x) and every
     position table's gradient; grid_r = 1 layers carry no table; more layers than one launch holds (17 > 16)."""
@@ -652,7 +653,12 @@ def test_layernorm_bwd_multi_equals_layer_by_layer(dev, name, dt, L_, D, side, r
         items.append((dy.to(dev), mean, rstd, ad, slot))
         ops.k_layernorm_bwd(dy.to(dev), xd, mean, rstd, add=ad, side=side, grid_r=r if r > 1 else 1, dx_acc=seq_acc)
     dx = acc0.clone().to(dev) if with_acc else torch.empty(rows, D, device=dev)
-    ops.k_layernorm_bwd_multi(xd, items, side, r if r > 1 else 1, dx, with_acc, dadd)
+    saved = L.knob_get(L.KNOB_LN_MULTI_CHUNK)
+    try:
+        L.knob_set(L.KNOB_LN_MULTI_CHUNK, chunk)          # layers per launch: every instantiation (2 / 4 / 5 / 6 / 7 sets of sums)
+        ops.k_layernorm_bwd_multi(xd, items, side, r if r > 1 else 1, dx, with_acc, dadd)
+    finally:
+        L.knob_set(L.KNOB_LN_MULTI_CHUNK, saved)
     assert rel_err(dx, ref_dx) < TOL[name]
     assert rel_err(dx, seq_acc) < 2e-6                       # same arithmetic, different summation order across layers
     k = 0

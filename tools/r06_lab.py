@@ -226,7 +226,7 @@ if "lnmulti" in verbs:   # the 13 SVA layers' LayerNorm backwards of the 9216-to
         items.append((rn(rows, D), mean, rstd, pos, l))
     acc = torch.zeros(rows, D, device=dev, dtype=f32)
     ref = None
-    for chunk in (4, 7):   # (104 / 107 = d(pos) sums by ds_add_f32 in LDS: built, 3.5x slower, removed — profiles/r06_lab.md)
+    for chunk in (4, 5, 6, 7):   # (104 / 107 = d(pos) sums by ds_add_f32 in LDS: built, 3.5x slower, removed — profiles/r06_lab.md)
         L.knob_set(L.KNOB_LN_MULTI_CHUNK, chunk)
         dadd = [torch.zeros(r * r, D, device=dev) for _ in range(Ln)]
         ops.k_layernorm_bwd_multi(x, items, side, r, acc, False, dadd)
@@ -240,7 +240,7 @@ if "lnmulti" in verbs:   # the 13 SVA layers' LayerNorm backwards of the 9216-to
         emit(case="lnmulti", chunk=chunk, us={k: round(v, 1) for k, v in us4.items()}, rel_diff_vs_chunk4=err,
              tbps_all13=round(rows * D * (2 * Ln + 2 * nl + 8 * nl - 4) / us4["all13"] / 1e6, 2),
              tbps_first4=round(rows * D * (2 * 4 + 2 + 4) / us4["first4"] / 1e6, 2))
-    L.knob_set(L.KNOB_LN_MULTI_CHUNK, 4)
+    L.knob_set(L.KNOB_LN_MULTI_CHUNK, 5)
 
 if "smallm" in verbs:
     a, w = rn(B, 1024), rn(1024, 1024, scale=1 / 32)
