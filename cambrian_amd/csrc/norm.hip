@@ -105,6 +105,101 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward of SEVERAL non-affine LayerNorms of the same input (round 6): the 13 SVA layers normalise the windowed tower's
+// 221 184 x 1024 tokens once each, only the position table differs (vision_sampler.py:304-309) — 13 launches of the kernel
+// above read x 13 times (52 bytes per element; 13 x 204 us per 24-image step).  Here a wave holds its row of x in registers
+// and walks the layers: 2 + 2 L bytes per element (28 at L = 13), the next row's loads in flight while the current row's L
+// outputs are reduced and written.  Per layer the arithmetic and its order are layernorm_fwd_kernel's: bit-identical.
+// ------------------------------------------------------------------------------------------------
+struct LnFwdMultiParams {
+  int layers;
+  const float* add[CMB_LN_MULTI_MAX];
+  void* y[CMB_LN_MULTI_MAX];
+  float* mean[CMB_LN_MULTI_MAX];
+  float* rstd[CMB_LN_MULTI_MAX];
+};
+
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) layernorm_fwd_multi_kernel(const T* __restrict__ x, int64_t rows, int D, int64_t ldx,
+                                                                  int side, int grid_r, float eps, const LnFwdMultiParams mp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nvec = D >> 3;
+  float nxt[NCH][8];
+  auto fetch = [&](int64_t row) {
+    if (row < rows) {
+      const T* xr = x + row * ldx;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int vi = lane + c * 64;
+        if (vi < nvec) Vec8<T>::load(xr + vi * 8, nxt[c]);
+      }
+    }
+  };
+  fetch(wave_global);
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    float xv[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[c][e] = nxt[c][e];
+    fetch(row + nwaves);
+    const int wp = window_pos((uint32_t)row, side, grid_r);
+    for (int l = 0; l < mp.layers; ++l) {
+      const float* ar = mp.add[l] ? mp.add[l] + (int64_t)wp * D : nullptr;
+      float v[NCH][8];
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int vi = lane + c * 64;
+        if (vi < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[c][e] = xv[c][e];
+          if (ar) {
+            float a[8];
+            load8f(ar + vi * 8, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] += a[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s += v[c][e];
+        }
+      }
+      const float mean = wave_sum(s) / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int vi = lane + c * 64;
+        if (vi < nvec) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[c][e] - mean;
+            q += d * d;
+          }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+      T* yr = (T*)mp.y[l] + row * (int64_t)D;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int vi = lane + c * 64;
+        if (vi < nvec) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd;
+          Vec8<T>::store(yr + vi * 8, o);
+        }
+      }
+      if (lane == 0) {
+        mp.mean[l][row] = mean;
+        mp.rstd[l][row] = rstd;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm forward, affine, no position table (the towers' LayerNorms: ViT blocks, ConvNeXt blocks): round 4.
 // The kernel above re-loads gamma and beta (2 x 4 D bytes of fp32) for every 2 D-byte row once D > 1024 — four times
 // the row's own bytes through the vector cache — and walks its rows one load -> reduce -> store round trip at a time
@@ -917,6 +1012,41 @@ extern "C" int cmb_layernorm_fwd(int dtype, const void* x, int64_t rows, int64_t
   if (dtype == CMB_F32)
     return ln_fwd<float>(x, rows, D, ldx, add, side, grid_r, gamma, beta, eps, y, ldy, mean, rstd, s);
   return CMB_ERR_BAD_ARG;
+}
+
+extern "C" int cmb_layernorm_fwd_multi(const cmb_ln_fwd_multi_desc* d, void* stream) {
+  if (!d || !d->x || d->rows < 0 || d->D <= 0 || (d->D & 7) || d->D > 1024 || (d->ldx & 7)) return CMB_ERR_BAD_ARG;
+  if (d->layers <= 0 || d->layers > CMB_LN_MULTI_MAX) return CMB_ERR_BAD_ARG;
+  if (d->dtype != CMB_BF16 && d->dtype != CMB_F32) return CMB_ERR_BAD_ARG;
+  int side = d->side, grid_r = d->grid_r;
+  bool any_add = false;
+  LnFwdMultiParams mp;
+  mp.layers = d->layers;
+  for (int l = 0; l < CMB_LN_MULTI_MAX; ++l) {
+    const bool on = l < d->layers;
+    if (on && (!d->y[l] || !d->mean[l] || !d->rstd[l])) return CMB_ERR_BAD_ARG;
+    any_add = any_add || (on && d->add[l]);
+    mp.add[l] = on ? d->add[l] : nullptr;
+    mp.y[l] = on ? d->y[l] : nullptr;
+    mp.mean[l] = on ? d->mean[l] : nullptr;
+    mp.rstd[l] = on ? d->rstd[l] : nullptr;
+  }
+  if (any_add && (side <= 0 || grid_r <= 0 || side % grid_r)) return CMB_ERR_BAD_ARG;
+  if (!any_add) { side = 1; grid_r = 1; }
+  if (d->rows == 0) return CMB_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = (d->rows + 15) / 16;   // ~4 rows per wave, each written `layers` times
+  if (blocks > 8192) blocks = 8192;
+  const int nch = nch_for(d->D);
+  if (nch != 2) return CMB_ERR_SHAPE;
+#define LN_FWD_MULTI(T_, NCH_)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_fwd_multi_kernel<T_, NCH_>), dim3((unsigned)blocks), dim3(256), 0, s, (const T_*)d->x, d->rows, \
+                     (int)d->D, d->ldx, side, grid_r, d->eps, mp)
+  if (d->dtype == CMB_BF16) LN_FWD_MULTI(bf16_t, 2);
+  else LN_FWD_MULTI(float, 2);
+#undef LN_FWD_MULTI
+  CMB_CHECK_LAUNCH();
+  return CMB_OK;
 }
 
 extern "C" int cmb_row_stats(int dtype, const void* x, int64_t rows, int64_t D, int64_t ldx, float eps, float* mean, float* rstd,

@@ -25,7 +25,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
 KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS, KNOB_LN_MULTI_CHUNK, KNOB_FLASH, KNOB_COLSUM_WGS, KNOB_LN_BWD_ROWS = 0, 1, 2, 3, 4, 5, 6, 7   # enum cmb_knob_id
-ABI_VERSION = 8   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
+ABI_VERSION = 9   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
           -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
@@ -116,6 +116,19 @@ class LnMultiDesc(C.Structure):
     ]
 
 
+class LnFwdMultiDesc(C.Structure):
+    """cmb_ln_fwd_multi_desc (include/cambrian_amd.h): forward of several non-affine LayerNorms of one input in one pass."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("layers", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("rows", C.c_int64), ("D", C.c_int64),
+        ("side", C.c_int32), ("grid_r", C.c_int32),
+        ("eps", C.c_float), ("reserved", C.c_int32),
+        ("add", C.c_void_p * LN_MULTI_MAX), ("y", C.c_void_p * LN_MULTI_MAX), ("mean", C.c_void_p * LN_MULTI_MAX),
+        ("rstd", C.c_void_p * LN_MULTI_MAX),
+    ]
+
+
 class ImageJob(C.Structure):
     """cmb_image_job (include/cambrian_amd.h): one (sample, tower) unit of the image pre-processing launch."""
     _fields_ = [
@@ -162,6 +175,7 @@ SIGNATURES = {
     "cmb_weight_prep": (C.c_int, [_p, _i32, _i64, _p]),
     "cmb_row_stats": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _f, _p, _p, _p]),
     "cmb_layernorm_bwd_multi": (C.c_int, [C.POINTER(LnMultiDesc), _p]),
+    "cmb_layernorm_fwd_multi": (C.c_int, [C.POINTER(LnFwdMultiDesc), _p]),
     "cmb_layernorm_fwd": (C.c_int, [C.c_int, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _f, _p, _i64, _p, _p, _p]),
     "cmb_layernorm_bwd": (C.c_int, [C.c_int, _p, _i64, _p, _i64, _i64, _i64, _p, _i32, _i32, _p, _p, _p, _p, _i64,
                                     _i32, _p, _p, _p, _p]),

@@ -63,10 +63,10 @@ typedef struct cmb_rowmap {
 const char* cmb_version(void);
 /* ABI revision: bumped whenever an entry point's signature or a descriptor's layout changes (round 2's key_valid
  * arguments = 2, round 3's fold_kv workspace = 3, the batch fields of cmb_gemm_desc = 4,
- * the kernel-selection knobs of round 4 = 5).  Bindings must compare it with the revision they
+ * the kernel-selection knobs of round 4 = 5, cmb_layernorm_fwd_multi = 9).  Bindings must compare it with the revision they
  * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
  * library still resolves, and a shifted argument list corrupts memory instead of failing. */
-#define CMB_ABI_VERSION 8
+#define CMB_ABI_VERSION 9
 int cmb_abi_version(void);
 
 /* Run-time kernel-selection knobs: which of several kernels that compute the SAME function an entry point launches
@@ -301,6 +301,26 @@ typedef struct cmb_ln_multi_desc {
   int32_t accumulate;
 } cmb_ln_multi_desc;
 int cmb_layernorm_bwd_multi(const cmb_ln_multi_desc* d, void* stream);
+
+/* Forward of SEVERAL non-affine LayerNorms of one input in one pass (round 6): y_l[r,:] = normalise(x[r,:] + add_l[pos(r),:]),
+ * l < layers — the 13 SVA layers' normalisations of the windowed tower's tokens (vision_sampler.py:304-309 reached 13 times per
+ * step on the SAME aux features; only the position table differs).  x is read once instead of `layers` times: 2 + 2 layers
+ * instead of 4 layers bytes per element.  Every y_l / mean_l / rstd_l equals, bit for bit, what cmb_layernorm_fwd(add = add_l,
+ * gamma = beta = NULL) returns.  add[l] may be NULL; y_l dense rows (leading dimension D); mean[l] / rstd[l] fp32 [rows],
+ * required.  layers <= CMB_LN_MULTI_MAX, D <= 1024 (D % 8 == 0). */
+typedef struct cmb_ln_fwd_multi_desc {
+  int32_t dtype;          /* CMB_BF16 | CMB_F32: element type of x and y_l */
+  int32_t layers;
+  const void* x;  int64_t ldx;
+  int64_t rows, D;
+  int32_t side, grid_r;
+  float eps;  int32_t reserved;
+  const float* add[CMB_LN_MULTI_MAX];
+  void* y[CMB_LN_MULTI_MAX];
+  float* mean[CMB_LN_MULTI_MAX];
+  float* rstd[CMB_LN_MULTI_MAX];
+} cmb_ln_fwd_multi_desc;
+int cmb_layernorm_fwd_multi(const cmb_ln_fwd_multi_desc* d, void* stream);
 
 /* RMSNorm: y = (x * rsqrt(mean(x^2)+eps)) * w, fp32 math, weight multiplied BEFORE the down-cast
  * (the reference's patched LlamaRMSNorm: train_fsdp.py:1429-1438; phi3/modeling_phi3.py:83-97). */
