@@ -85,17 +85,24 @@ def test_linear_inside_a_window_is_the_same_function_and_never_stale(dev):
     y1, g1 = run(True)          # weights seen for the first time: prepared on the spot, registered
     assert len(ops._PREP) == n_before + 3
     y2, g2 = run(True)          # second step: one cmb_weight_prep launch refreshes all three
+    def same(ga, gb):
+        # weight / input gradients bit for bit; the bias gradient is cmb_colsum's fp32 atomics (order not fixed —
+        # with round 6's rows per workgroup 384 rows are 24 partial sums, not 2)
+        for i, (a, b) in enumerate(zip(ga, gb)):
+            if i == 1:
+                assert torch.allclose(a, b, rtol=2e-6, atol=0)
+            else:
+                assert torch.equal(a, b)
+
     for y, gs in ((y1, g1), (y2, g2)):
         assert torch.equal(y, y0)
-        for a, b in zip(gs, g0):
-            assert torch.equal(a, b)
+        same(gs, g0)
     with torch.no_grad():       # an optimizer step: the next window serves the NEW weights
         lin.weight.mul_(0.5)
         wide.add_(0.01)
     y3, g3 = run(True)
     y4, g4 = run(False)
     assert torch.equal(y3, y4) and not torch.equal(y3, y0)
-    for a, b in zip(g3, g4):
-        assert torch.equal(a, b)
+    same(g3, g4)
     # outside a window nothing is served from the cache
     assert ops.prepared_weight(lin.weight, torch.bfloat16) is None

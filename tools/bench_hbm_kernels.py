@@ -51,6 +51,14 @@ def cases():
         return lambda: ops.k_layernorm_fwd(x, None, None, 1e-5, add=pos, side=96, grid_r=4)
     add("layernorm_fwd [SVA xhat, ConvNeXt tower]", "layernorm_fwd_kernel", f"{rows}x{D}", rows * D * 2 * 2 + rows * 8, mk_svan)
 
+    def mk_svan_multi(rows=rows, D=D):
+        x = rn(rows, D)
+        adds = [rn(16, D, dtype=f32) for _ in range(13)]
+        return lambda: ops.k_layernorm_fwd_multi(x, adds, 1e-5, 96, 4)
+    # x once, 13 normalised outputs + their statistics
+    add("layernorm_fwd_multi [the 13 SVA layers' xhat of the ConvNeXt tower, one pass]", "layernorm_fwd_multi_kernel",
+        f"{rows}x{D} x 13 layers", rows * D * 2 * 14 + 13 * rows * 8, mk_svan_multi)
+
     def mk_svanb(rows=rows, D=D):
         x, dn, pos = rn(rows, D), rn(rows, D), rn(16, D, dtype=f32)
         _, mean, rstd = ops.k_layernorm_fwd(x, None, None, 1e-5, add=pos, side=96, grid_r=4)
@@ -70,10 +78,10 @@ def cases():
             dadd.append(torch.zeros(16, D, device=dev, dtype=f32))
         acc = torch.empty(rows, D, device=dev, dtype=f32)
         return lambda: ops.k_layernorm_bwd_multi(x, items, 96, 4, acc, False, dadd)
-    # 13 layers in launches of 4 + 4 + 4 + 1: x read per launch (4 x 2), every gradient once (13 x 2), the fp32 sum written by
-    # each launch and re-read by the next three (4 x 4 + 3 x 4)
+    # 13 layers in launches of 5 + 5 + 3 (round 6; 4 + 4 + 4 + 1 before): x read per launch (3 x 2), every gradient once (13 x 2),
+    # the fp32 sum written by each launch and re-read by the next two (3 x 4 + 2 x 4)
     add("layernorm_bwd_multi [the 13 SVA layers of the ConvNeXt tower, one deferred pass]", "layernorm_bwd_multi_kernel",
-        f"{rows}x{D} x 13 layers", rows * D * (4 * 2 + 13 * 2 + 4 * 4 + 3 * 4), mk_multi)
+        f"{rows}x{D} x 13 layers", rows * D * (3 * 2 + 13 * 2 + 3 * 4 + 2 * 4), mk_multi)
 
     def mk_lnb(D=D):
         r2 = B * 576
