@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--tower-recompute", action="store_true",
                     help="with --unfreeze-towers: per-block activation re-computation inside the four towers")
     ap.add_argument("--bucket-mb", type=float, default=64.0, help="gradient bucket size of GradSync / ZeRO-2 (MiB)")
+    ap.add_argument("--bf16-buckets", action="store_true",
+                    help="opt-in: GradSync's all-reduce on bf16 copies of the fp32 buckets (half the exchange; the mean to bf16 "
+                         "rounding; marks the line NOT_HEADLINE)")
     ap.add_argument("--scored-rows", action="store_true",
                     help="lm_head + cross-entropy only over the scored positions (config.fused_loss = 'scored_rows': shifted label != "
                          "-100; identical loss and gradients, no logits returned) — NOT the headline line, which computes every row "
@@ -752,7 +755,7 @@ def main():
         sync = GradSync(params, bucket_mb=args.bucket_mb)
     else:
         opt = torch.optim.AdamW(params, lr=lr, weight_decay=0.0, fused=True)
-        sync = GradSync(params, bucket_mb=args.bucket_mb)
+        sync = GradSync(params, bucket_mb=args.bucket_mb, comm_dtype=torch.bfloat16 if args.bf16_buckets else None)
     if args.comm_only:
         return comm_only(args, rank, world, dev, params, opt, sync)
     if args.batch <= 0:   # default: what fits the device with headroom
@@ -949,6 +952,8 @@ def main():
         if args.fp8_projections:
             line["dtype"] = "bf16 + fp8 (e4m3, row-wise scales) forward GEMMs of the KV-side SVA projections"
             line["config"]["NOT_HEADLINE"] = "reduced-precision mode of BASELINE configs[4]; the headline line is the bf16 run"
+        if args.bf16_buckets:
+            line["config"]["NOT_HEADLINE"] = "gradient all-reduce on bf16 copies of the fp32 buckets (opt-in; the headline exchanges fp32)"
         if masked is not None:
             line["masked_case"] = masked
         if multi_gpu is not None:

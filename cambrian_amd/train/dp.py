@@ -38,14 +38,21 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.work = None
+        self.wire = None     # the buffer the collective runs on when GradSync.comm_dtype differs from the gradients' dtype
 
 
 class GradSync:
     """Bucketed all-reduce(mean) of the gradients of ``params`` overlapped with backward."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 64.0,
-                 process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
-        """``always_reduce``: issue the collectives even at world size 1 (tests: the RCCL path on a one-GPU box)."""
+                 process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False,
+                 comm_dtype: Optional[torch.dtype] = None):
+        """``always_reduce``: issue the collectives even at world size 1 (tests: the RCCL path on a one-GPU box).
+        ``comm_dtype`` (opt-in, e.g. torch.bfloat16): the collective runs on a copy of the bucket in that dtype — each rank's
+        gradients are divided by the world size first, cast, summed on the wire, cast back (half the bytes of the fp32
+        exchange: 0.6 instead of 1.2 GB per step at the pre-training stage; the mean is then exact only to the wire dtype's
+        rounding, 2^-9 relative per addend for bf16 — the default stays the gradients' own dtype)."""
+        self.comm_dtype = comm_dtype
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reduce = self.world > 1 or (always_reduce and dist.is_initialized())
@@ -85,7 +92,16 @@ class GradSync:
                     b.views[k].zero_()
                 q.grad = b.views[k]
             if self.reduce:
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        if self.comm_dtype is None or self.comm_dtype == b.flat.dtype:
+            return dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b.wire is None:
+            b.wire = torch.empty(b.numel, device=b.flat.device, dtype=self.comm_dtype)
+        torch.div(b.flat, self.world, out=b.flat)      # the mean's scale BEFORE the narrow cast: the wire carries gradient-sized values
+        b.wire.copy_(b.flat)
+        return dist.all_reduce(b.wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         """Call after ``loss.backward()``: waits for the collectives and turns sums into means."""
@@ -101,11 +117,14 @@ class GradSync:
                             b.views[i].copy_(p.grad)
                         p.grad = b.views[i]
                 if self.reduce:
-                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b.work = self._launch(b)
             if b.work is not None:
                 b.work.wait()
                 b.work = None
-                b.flat.div_(self.world)
+                if b.wire is not None:
+                    b.flat.copy_(b.wire)               # already the mean (divided before the cast)
+                else:
+                    b.flat.div_(self.world)
             b.pending = len(b.params)
 
     def reset(self) -> None:

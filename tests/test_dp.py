@@ -3,6 +3,7 @@ yields exactly the mean of the per-rank gradients, including parameters that rec
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -20,7 +21,7 @@ def _model():
                                torch.nn.Linear(32, 4))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, comm_dtype=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from cambrian_amd.train.dp import GradSync, init_distributed
@@ -29,7 +30,7 @@ def _worker(rank, world, port, q):
     m = _model()
     unused = torch.nn.Parameter(torch.ones(5))         # never used in the loss: must still sync (as zero)
     params = list(m.parameters()) + [unused]
-    sync = GradSync(params, bucket_mb=0.002)           # tiny buckets -> several collectives
+    sync = GradSync(params, bucket_mb=0.002, comm_dtype=comm_dtype)   # tiny buckets -> several collectives
     assert len(sync.buckets) > 2
     data = [torch.randn(8, 16, generator=torch.Generator().manual_seed(10 + k)) for k in range(world)]
     for step in range(2):                               # two steps: buckets are reusable
@@ -46,17 +47,22 @@ def _worker(rank, world, port, q):
         gk = [p.grad for p in mk.parameters()] + [torch.zeros(5)]
         want = gk if want is None else [a + b for a, b in zip(want, gk)]
     want = [g / world for g in want]
-    ok = all(torch.allclose(a, b, atol=1e-6, rtol=1e-5) for a, b in zip(got, want))
+    if comm_dtype is None:
+        ok = all(torch.allclose(a, b, atol=1e-6, rtol=1e-5) for a, b in zip(got, want))
+    else:   # bf16 on the wire: the mean to the wire's rounding (1e-2 against the fp32 buckets), fp32 slots
+        ok = all(a.dtype == torch.float32 and float((a - b).abs().max()) <= 1e-2 * float(b.abs().max()) + 1e-12 for a, b in zip(got, want))
+        ok = ok and any(not torch.equal(a, b) for a, b in zip(got, want))   # ... and it really went through the narrow dtype
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gradsync_world2_gloo():
+@pytest.mark.parametrize("comm_dtype", [None, torch.bfloat16])
+def test_gradsync_world2_gloo(comm_dtype):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, comm_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
