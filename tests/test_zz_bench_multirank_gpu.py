@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", [[], ["--zero3"]])
+@pytest.mark.parametrize("mode", [[], ["--zero3"], ["--bf16-buckets"]])
 def test_two_ranks_one_json_line(dev, mode):
     env = dict(os.environ, CAMBRIAN_DIST_BACKEND="gloo", CAMBRIAN_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                CAMBRIAN_AMD_RANDOM_INIT="1")
-    port = 29600 + os.getpid() % 300 + (7 if mode else 0)
+    port = 29600 + os.getpid() % 300 + {"": 0, "--zero3": 7, "--bf16-buckets": 13}[mode[0] if mode else ""]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--batch", "2", "--llm-layers", "2", "--no-cpu-baseline", "--no-masked-case"] + mode
@@ -29,7 +29,8 @@ def test_two_ranks_one_json_line(dev, mode):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     assert d["value"] == pytest.approx(4 / (d["ms_per_step"] * 1e-3), rel=1e-6)    # whole-job images / max-over-ranks time
-    assert ("zero3" in d["config"]["parallelism"]) == bool(mode)
+    assert ("zero3" in d["config"]["parallelism"]) == (mode == ["--zero3"])
+    assert ("bf16 copies" in d["config"].get("NOT_HEADLINE", "")) == (mode == ["--bf16-buckets"])   # opt-in wire dtype: never headline
 
 
 def test_plain_launch_spawns_its_own_ranks(dev):
