@@ -113,7 +113,8 @@ class VisionCrossAttentionLayer(nn.Module):
         # proj_context + proj_in (vision_sampler.py:279-292) without the concat
         c = ops.linear(ctx2, self.proj_context.weight)
         cb = ops.linear(c, self.proj_in.weight[:, Dq:])
-        x = ops.linear(q2, self.proj_in.weight[:, :Dq], residual=cb, res_rep=ctx_rep)
+        link = {}   # q2 is used twice (here and as the block's residual): the two gradients meet in this GEMM's backward (ops.LinearFn)
+        x = ops.linear(q2, self.proj_in.weight[:, :Dq], residual=cb, res_rep=ctx_rep, link=link, role=1)
         # Q (vision_sampler.py:187)
         xn = ops.layernorm(x, ca.q_proj[0].weight, ca.q_proj[0].bias, ca.q_proj[0].eps)
         qh = ops.linear(xn, ca.q_proj[1].weight)
@@ -144,7 +145,7 @@ class VisionCrossAttentionLayer(nn.Module):
         y0 = ops.linear(o, ca.o_proj.weight, residual=x)                        # x + attn  (:319)
         y = ops.layernorm(y0, self.norm.weight, self.norm.bias, self.norm.eps)   # :321
         h = ops.linear(y, self.proj_out.linear_1.weight, act=L.ACT_GELU_ERF)     # :323
-        return ops.linear(h, self.proj_out.linear_2.weight, residual=q2)         # + residual (:325)
+        return ops.linear(h, self.proj_out.linear_2.weight, residual=q2, link=link, role=2)   # + residual (:325)
 
     def _absorbed_tower(self, qh: torch.Tensor, feats) -> int:
         """Index of the tower whose K / V projections are absorbed into the query side, or -1: bf16 (MFMA kernels) or fp32

@@ -816,8 +816,21 @@ class LinearFn(torch.autograd.Function):
     (the per-image context term of proj_in, vision_sampler.py:279-292, never materialised per query)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act: int, residual, res_rep: int, colscale, heavy: bool = False):
+    def forward(ctx, x, weight, bias, act: int, residual, res_rep: int, colscale, heavy: bool = False, link=None, role: int = 0):
         dt = x.dtype
+        # ``link`` (a dict private to one block) joins the two uses of a block's input t — y1 = linear(t, ...) (role 1, the
+        # "sink") ... out = linear(h, ..., residual=t) (role 2, the "source"): autograd would sum d(t) = g1 W1 + d(out) with an
+        # ATen add over [rows, width]; the source's backward (it always runs first: its input descends from the sink's output)
+        # parks d(out) in the link instead of returning it and the sink's d(x) GEMM adds it in its epilogue.
+        ctx.link = None
+        if link is not None and LINK_RESIDUAL_GRADS:
+            if role == 1 and ctx.needs_input_grad[0]:
+                link["armed"] = (x.data_ptr(), tuple(x.shape))
+                ctx.link = link
+            elif role == 2 and residual is not None and res_rep == 0 and ctx.needs_input_grad[4] and residual.dtype == dt \
+                    and residual.is_contiguous() and link.get("armed") == (residual.data_ptr(), tuple(residual.shape)):
+                ctx.link = link
+        ctx.role = role
         prep = prepared_weight(weight, dt)
         w_c, ctx.w_t = prep if prep is not None else (k_cast(weight, dt), None)
         b_c = None if bias is None else k_cast(bias, torch.float32)
@@ -856,7 +869,10 @@ class LinearFn(torch.autograd.Function):
         N = w_c.shape[0]
         dres = None
         if need_res:
-            dres = k_segment_sum(dy, ctx.res_rep) if ctx.res_rep > 0 else dy
+            if ctx.link is not None and ctx.role == 2:
+                ctx.link["g"] = dy                      # handed to the sink's d(x) GEMM (see forward)
+            else:
+                dres = k_segment_sum(dy, ctx.res_rep) if ctx.res_rep > 0 else dy
         g = dy
         if colscale is not None:
             g = dy * colscale.to(dt)  # LayerScale belongs to the frozen towers; kept for completeness
@@ -871,12 +887,15 @@ class LinearFn(torch.autograd.Function):
         if need_x:
             n_pad = pad_to(N, ks)
             w_t = ctx.w_t if (ctx.w_t is not None and ctx.w_t.shape[1] == n_pad) else k_transpose(w_c, n_pad)  # [K, N_pad]
+            parked = ctx.link.pop("g", None) if (ctx.link is not None and ctx.role == 1) else None
             if n_pad != N:
                 gpad = torch.zeros((M, n_pad), dtype=dt, device=g.device)
                 gpad[:, :N] = g
-                dx = k_gemm(gpad, w_t)
+                dx = k_gemm(gpad, w_t, residual=parked)
             else:
-                dx = k_gemm(g, w_t)
+                dx = k_gemm(g, w_t, residual=parked)
+        elif ctx.link is not None and ctx.role == 1 and "g" in ctx.link:
+            dx = ctx.link.pop("g")                       # (never expected: the sink was armed because x requires grad)
         if need_w:
             if (dt == torch.bfloat16 and M > 0 and N % 8 == 0 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0
                     and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0 and g.stride(1) == 1 and g.stride(0) % 8 == 0
@@ -894,16 +913,20 @@ class LinearFn(torch.autograd.Function):
             db = k_colsum(g)
             if ctx.b_dtype != torch.float32:
                 db = db.to(ctx.b_dtype)
-        return dx, dw, db, None, dres, None, None, None
+        return dx, dw, db, None, dres, None, None, None, None, None
+
+
+# CAMBRIAN_AMD_LINK_RESIDUAL_GRADS=0: autograd sums the two gradients of a block's input itself (A/B runs)
+LINK_RESIDUAL_GRADS = os.environ.get("CAMBRIAN_AMD_LINK_RESIDUAL_GRADS", "1") != "0"
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE,
            residual: Optional[torch.Tensor] = None, res_rep: int = 0,
-           colscale: Optional[torch.Tensor] = None, heavy: bool = False) -> torch.Tensor:
+           colscale: Optional[torch.Tensor] = None, heavy: bool = False, link: Optional[dict] = None, role: int = 0) -> torch.Tensor:
     """2-D linear on the HIP GEMM.  x [M,K] -> [M,N].  ``heavy`` marks the KV-side projections (aux projectors, SVA
     K/V projections: M = every tower token, >85 % of the SVA-side FLOPs) — the ones ``fp8_projections`` moves to the
-    fp8 MFMA; the query-side GEMMs (M = 576 per image) stay bf16."""
-    return LinearFn.apply(x, weight, bias, act, residual, res_rep, colscale, heavy)
+    fp8 MFMA; the query-side GEMMs (M = 576 per image) stay bf16.  ``link`` / ``role``: see LinearFn.forward."""
+    return LinearFn.apply(x, weight, bias, act, residual, res_rep, colscale, heavy, link, role)
 
 
 # ================================================================================================
