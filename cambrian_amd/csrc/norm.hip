@@ -511,6 +511,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(
 // ------------------------------------------------------------------------------------------------
 struct LnMultiParams {
   int layers;
+  void* dx_out;   // non-null: this launch writes the finished sum here in x's dtype (dense rows) instead of updating dx
   const void* dy[CMB_LN_MULTI_MAX];
   const float* add[CMB_LN_MULTI_MAX];
   const float* mean[CMB_LN_MULTI_MAX];
@@ -617,7 +618,10 @@ layernorm_bwd_multi_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, i
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int vi = lane + c * 64;
-      if (vi < nvec) Vec8<float>::store(dx + row * lddx + vi * 8, acc[c]);
+      if (vi < nvec) {
+        if (mp.dx_out) Vec8<T>::store(reinterpret_cast<T*>(mp.dx_out) + row * (int64_t)D + vi * 8, acc[c]);   // (block-uniform)
+        else Vec8<float>::store(dx + row * lddx + vi * 8, acc[c]);
+      }
     }
   }
   // block-level combine of each layer's partial sums through sred[4][D], then one atomicAdd per column per workgroup
@@ -1128,6 +1132,7 @@ extern "C" int cmb_layernorm_bwd_multi(const cmb_ln_multi_desc* d, void* stream)
   for (int l0 = 0; l0 < d->layers; l0 += kChunk) {
     LnMultiParams mp;
     mp.layers = d->layers - l0 < kChunk ? d->layers - l0 : kChunk;
+    mp.dx_out = (l0 + kChunk >= d->layers) ? d->dx_out : nullptr;   // the call's last launch
     for (int l = 0; l < CMB_LN_MULTI_MAX; ++l) {
       const bool on = l < mp.layers;
       mp.dy[l] = on ? d->dy[l0 + l] : nullptr;

@@ -25,7 +25,7 @@ ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_erf":
              "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU}
 SVA_MAX_TOWERS = 8
 KNOB_LN_FWD, KNOB_DWCONV, KNOB_VIT_ATTN, KNOB_SVA_ABS, KNOB_LN_MULTI_CHUNK, KNOB_FLASH, KNOB_COLSUM_WGS, KNOB_LN_BWD_ROWS = 0, 1, 2, 3, 4, 5, 6, 7   # enum cmb_knob_id
-ABI_VERSION = 9   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
+ABI_VERSION = 10   # CMB_ABI_VERSION of the include/cambrian_amd.h this binding was written against
 
 STATUS = {0: "CMB_OK", -1: "CMB_ERR_BAD_ARG", -2: "CMB_ERR_ALIGNMENT", -3: "CMB_ERR_SHAPE",
           -4: "CMB_ERR_WORKSPACE", -5: "CMB_ERR_LAUNCH"}
@@ -112,7 +112,8 @@ class LnMultiDesc(C.Structure):
         ("dy", C.c_void_p * LN_MULTI_MAX), ("add", C.c_void_p * LN_MULTI_MAX), ("mean", C.c_void_p * LN_MULTI_MAX),
         ("rstd", C.c_void_p * LN_MULTI_MAX), ("dadd", C.c_void_p * LN_MULTI_MAX),
         ("dx", C.c_void_p), ("lddx", C.c_int64),
-        ("accumulate", C.c_int32),
+        ("accumulate", C.c_int32), ("reserved", C.c_int32),
+        ("dx_out", C.c_void_p),
     ]
 
 

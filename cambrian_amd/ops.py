@@ -962,6 +962,11 @@ DEFER_LN_BWD = os.environ.get("CAMBRIAN_AMD_DEFER_LN_BWD", "1") != "0"   # (A/B 
 DEFER_LN_FLUSH = int(os.environ.get("CAMBRIAN_AMD_DEFER_LN_FLUSH", "5"))
 
 
+# the last multi-layer launch of a tower's deferred LayerNorm backward writes d(x) in x's dtype (no separate cast of the fp32
+# accumulator); CAMBRIAN_AMD_LN_BWD_FINAL_CAST=0: accumulator + cmb_cast as before (A/B runs)
+LN_BWD_FINAL_CAST = os.environ.get("CAMBRIAN_AMD_LN_BWD_FINAL_CAST", "1") != "0"
+
+
 class GradAccumulator:
     """fp32 side buffer that the 13 SVA layers' LayerNorm backwards accumulate into (all layers read the
     same aux feature tensor; SURVEY.md §7 "hard parts").
@@ -990,14 +995,14 @@ class GradAccumulator:
             self.buf = torch.zeros((rows, D), dtype=torch.float32, device=device)
         return self.buf
 
-    def flush(self) -> None:
+    def flush(self, final_dtype: Optional[torch.dtype] = None) -> Optional[torch.Tensor]:
         """Run the parked LayerNorm backwards (one cmb_layernorm_bwd_multi call per window geometry) into the shared fp32
         buffer and release their gradient tensors.  Called by SvaNormFn.backward whenever DEFER_LN_FLUSH layers are parked
         (= the kernel's 5-layer launches: same launches as one call at the end, but at most 5 layers' d(x-hat) — 2.3 GB at
         24 images instead of 5.9 GB — are alive at a time) and by SharedGradFn.backward for the rest."""
         items, self.deferred = self.deferred, []
         if not items:
-            return
+            return None
         x = items[0][1]
         groups = {}
         for dn, _x, mean, rstd, add, side, grid_r, slot in items:
@@ -1007,16 +1012,27 @@ class GradAccumulator:
         have = self.buf is not None
         if self.buf is None:
             self.buf = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        # ``final_dtype`` (SharedGradFn.backward's last flush): the kernel's last launch writes the finished sum in that dtype —
+        # the fp32 accumulator's cast (906 MB read + 453 MB written for the 9216-token tower at 24 images) and the launch's own
+        # fp32 write are gone.  Returns that tensor (the accumulator is then stale), else None.
+        out = None
+        if final_dtype is not None and final_dtype == x.dtype and final_dtype != torch.float32 and len(groups) == 1:
+            out = torch.empty((x.shape[0], x.shape[1]), dtype=final_dtype, device=x.device)
         for (side, grid_r), its in groups.items():
-            k_layernorm_bwd_multi(x, its, side, grid_r, self.buf, have, self.dpos)
+            k_layernorm_bwd_multi(x, its, side, grid_r, self.buf, have, self.dpos, dx_out=out)
             have = True
+        return out
 
 
-def k_layernorm_bwd_multi(x: torch.Tensor, items, side: int, grid_r: int, dx: torch.Tensor, accumulate: bool, dadd_out):
+def k_layernorm_bwd_multi(x: torch.Tensor, items, side: int, grid_r: int, dx: torch.Tensor, accumulate: bool, dadd_out,
+                          dx_out: Optional[torch.Tensor] = None):
     """cmb_layernorm_bwd_multi over ``items`` = [(dn, mean, rstd, add | None, slot)]: dx (fp32 [rows, D]) (+)= the summed
-    LayerNorm backwards; ``dadd_out[slot]`` (fp32, zero-filled, same shape as the table) receives each layer's table gradient."""
-    L.require_gpu(x, dx)
+    LayerNorm backwards; ``dadd_out[slot]`` (fp32, zero-filled, same shape as the table) receives each layer's table gradient.
+    ``dx_out`` (x's dtype, dense [rows, D]): the last launch writes the finished sum THERE instead of updating dx."""
+    L.require_gpu(x, dx, dx_out)
     rows, D = x.shape
+    if dx_out is not None and (dx_out.dtype != x.dtype or not dx_out.is_contiguous() or tuple(dx_out.shape) != (rows, D)):
+        raise L.CambrianAmdError("layernorm_bwd_multi: dx_out must be a dense [rows, D] tensor of x's dtype")
     for lo in range(0, len(items), L.LN_MULTI_MAX):
         chunk = items[lo:lo + L.LN_MULTI_MAX]
         d = L.LnMultiDesc()
@@ -1029,6 +1045,7 @@ def k_layernorm_bwd_multi(x: torch.Tensor, items, side: int, grid_r: int, dx: to
             d.add[i] = None if add is None else add.data_ptr()
             d.dadd[i] = None if (add is None or slot < 0 or dadd_out[slot] is None) else dadd_out[slot].data_ptr()
         d.dx, d.lddx, d.accumulate = dx.data_ptr(), dx.stride(0), 1 if (accumulate or lo > 0) else 0
+        d.dx_out = dx_out.data_ptr() if (dx_out is not None and lo + L.LN_MULTI_MAX >= len(items)) else None
         L.check(L.load().cmb_layernorm_bwd_multi(C.byref(d), L.stream_ptr(x.device)), "cmb_layernorm_bwd_multi")
 
 
@@ -1054,11 +1071,13 @@ class SharedGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         h = ctx.holder
-        h.flush()
+        done = h.flush(final_dtype=ctx.x_dtype if (g is None and LN_BWD_FINAL_CAST) else None)
         buf, h.buf = h.buf, None
         dpos = [None if t is None else (t if h.pos_meta[i][1] == torch.float32 else t.to(h.pos_meta[i][1]))
                 for i, t in enumerate(h.dpos)] + [None] * (ctx.n_pos - len(h.dpos))
         h.dpos = [None] * ctx.n_pos
+        if done is not None:     # the last multi-layer launch already wrote d(x) in x's dtype
+            return (done.view(h.shape), None, *dpos)
         if buf is None:
             return (g, None, *dpos)
         if g is not None:

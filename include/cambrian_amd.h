@@ -63,10 +63,10 @@ typedef struct cmb_rowmap {
 const char* cmb_version(void);
 /* ABI revision: bumped whenever an entry point's signature or a descriptor's layout changes (round 2's key_valid
  * arguments = 2, round 3's fold_kv workspace = 3, the batch fields of cmb_gemm_desc = 4,
- * the kernel-selection knobs of round 4 = 5, cmb_layernorm_fwd_multi = 9).  Bindings must compare it with the revision they
+ * the kernel-selection knobs of round 4 = 5, cmb_layernorm_fwd_multi = 9, cmb_ln_multi_desc.dx_out = 10).  Bindings must compare it with the revision they
  * were written against (CMB_ABI_VERSION; cambrian_amd/lib.py::load raises on a mismatch): every symbol of a stale
  * library still resolves, and a shifted argument list corrupts memory instead of failing. */
-#define CMB_ABI_VERSION 9
+#define CMB_ABI_VERSION 10
 int cmb_abi_version(void);
 
 /* Run-time kernel-selection knobs: which of several kernels that compute the SAME function an entry point launches
@@ -299,6 +299,10 @@ typedef struct cmb_ln_multi_desc {
   float* dadd[CMB_LN_MULTI_MAX];
   float* dx;      int64_t lddx;
   int32_t accumulate;
+  int32_t reserved;
+  void* dx_out;           /* optional (round 6): the call's LAST launch writes the finished sum here in x's dtype (dense rows,
+                           * leading dimension D) instead of updating dx — the cast of the fp32 accumulator at the end of the
+                           * deferred backward; dx then holds the sum without the last launch's layers */
 } cmb_ln_multi_desc;
 int cmb_layernorm_bwd_multi(const cmb_ln_multi_desc* d, void* stream);
 

@@ -661,6 +661,18 @@ def test_layernorm_bwd_multi_equals_layer_by_layer(dev, name, dt, L_, D, side, r
         L.knob_set(L.KNOB_LN_MULTI_CHUNK, saved)
     assert rel_err(dx, ref_dx) < TOL[name]
     assert rel_err(dx, seq_acc) < 2e-6                       # same arithmetic, different summation order across layers
+    # dx_out: the call's last launch writes the finished sum in x's dtype instead of updating the fp32 accumulator
+    dx2 = acc0.clone().to(dev) if with_acc else torch.empty(rows, D, device=dev)
+    out16 = torch.empty(rows, D, device=dev, dtype=dt)
+    dadd2 = [torch.zeros_like(t) for t in dadd]
+    try:
+        L.knob_set(L.KNOB_LN_MULTI_CHUNK, chunk)
+        ops.k_layernorm_bwd_multi(xd, items, side, r if r > 1 else 1, dx2, with_acc, dadd2, dx_out=out16)
+    finally:
+        L.knob_set(L.KNOB_LN_MULTI_CHUNK, saved)
+    assert torch.equal(out16, dx.to(dt))                     # the same fp32 sum, rounded once
+    for a, b in zip(dadd2, dadd):
+        assert rel_err(a, b) < 2e-6
     k = 0
     for a in ars:
         if a is not None:
