@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_nt_kernel(const GemmParams p
     p.A += bz * p.a_bs * (int64_t)sizeof(T);
     p.B += bz * p.b_bs * (int64_t)sizeof(T);
     p.C += bz * p.c_bs * (int64_t)(p.out_f32 ? 4 : sizeof(typename Mfma<T>::out_t));
+    if (p.R) p.R += bz * p.c_bs * (int64_t)sizeof(T);   // a batched residual is laid out as C (same batch stride)
   }
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
@@ -406,8 +407,10 @@ int gemm_params_from_desc(const cmb_gemm_desc* d, GemmParams& p, int& splits) {
        sizeof(T) == 1))
     return CMB_ERR_BAD_ARG;   // the gated epilogue writes an N / 2 wide C of the operand dtype and nothing else
   if (p.batch > 1) {
-    // batched problems: plain epilogue (alpha / activation / out dtype), no split-K, 16-byte aligned strides
-    if (splits > 1 || d->bias || d->colscale || d->residual || d->pre_out || sizeof(T) == 1) return CMB_ERR_BAD_ARG;
+    // batched problems: plain epilogue (alpha / activation / out dtype; a residual laid out as C: its batch stride is C's), no
+    // split-K, 16-byte aligned strides
+    if (splits > 1 || d->bias || d->colscale || d->pre_out || sizeof(T) == 1) return CMB_ERR_BAD_ARG;
+    if (d->residual && (d->out_dtype != d->dtype)) return CMB_ERR_BAD_ARG;
     if ((p.a_bs * (int64_t)sizeof(T)) % 16 || (p.b_bs * (int64_t)sizeof(T)) % 16 || (p.c_bs * 2) % 16) return CMB_ERR_ALIGNMENT;
   }
   if constexpr (sizeof(T) == 1) {

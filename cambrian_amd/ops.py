@@ -1265,7 +1265,7 @@ def sva_attention(q, kvs: Sequence[torch.Tensor], masks, r_list, B, qside, heads
 # absorbed K / V projections of the windowed tower (csrc/sva_absorbed.hip)
 # ================================================================================================
 def k_gemm_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch: int, M: int, N: int, K: int, lda: int,
-                   ldb: int, ldc: int, a_bs: int, b_bs: int, c_bs: int) -> torch.Tensor:
+                   ldb: int, ldc: int, a_bs: int, b_bs: int, c_bs: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``batch`` independent C_z[M,N] = A_z[M,K] @ B_z[N,K]^T in one launch (cmb_gemm, 128 x 128 tile): problem z reads
     A + z*a_bs (row stride lda), B + z*b_bs (row stride ldb) and writes C + z*c_bs (row stride ldc), all in elements of
     the tensors' dtype (``out`` may be fp32 for bf16 operands).  The per-head GEMMs of the absorbed SVA projections."""
@@ -1280,6 +1280,12 @@ def k_gemm_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, batch
     d.C, d.c_map = out.data_ptr(), L.identity_map(ldc)
     d.bias = d.colscale = d.residual = d.pre_out = None
     d.r_map = d.p_map = L.identity_map(0)
+    if residual is not None:   # laid out as ``out`` (row stride ldc, batch stride c_bs), the operands' dtype
+        L.require_gpu(residual)
+        if residual.dtype != a.dtype or out.dtype != a.dtype or residual.stride(-1) != 1 or residual.stride(0) != ldc \
+                or residual.data_ptr() % 16:
+            raise L.CambrianAmdError("batched gemm residual must have the operands' dtype and the output's layout")
+        d.residual, d.r_map = residual.data_ptr(), L.identity_map(ldc)
     d.act, d.alpha, d.beta, d.split_k, d.tile_hint = L.ACT_NONE, 1.0, 0.0, 1, 0
     d.workspace, d.workspace_bytes = None, 0
     d.batch, d.a_batch_stride, d.b_batch_stride, d.c_batch_stride = batch, a_bs, b_bs, c_bs
@@ -1361,7 +1367,9 @@ class HeadContractFn(torch.autograd.Function):
     batched launch; backward: dXb_h = dy_h W_h (K = 64), dW_h = dy_h^T Xb_h."""
 
     @staticmethod
-    def forward(ctx, xb, w, heads: int):
+    def forward(ctx, xb, w, heads: int, addend=None):
+        """``addend`` [Bq, C] (optional): y = addend + the per-head products, added in the GEMM's epilogue (the one-key towers'
+        part of the attention output: no separate add over [Bq, C])."""
         Bq, H, Cin = xb.shape
         C = w.shape[0]
         hd = C // heads
@@ -1369,8 +1377,10 @@ class HeadContractFn(torch.autograd.Function):
         w_c, ctx.w_t = prep if (prep is not None and prep[1].shape[1] == C) else (k_cast(w, xb.dtype), None)
         xbc = xb if xb.is_contiguous() else xb.contiguous()
         y = torch.empty((Bq, C), dtype=xb.dtype, device=xb.device)
+        if addend is not None:
+            addend = _as_dtype_contig(addend, xb.dtype)
         k_gemm_batched(xbc, w_c, y, batch=heads, M=Bq, N=hd, K=Cin, lda=heads * Cin, ldb=Cin, ldc=C, a_bs=Cin,
-                       b_bs=hd * Cin, c_bs=hd)
+                       b_bs=hd * Cin, c_bs=hd, residual=addend)
         ctx.save_for_backward(xbc, w_c)
         ctx.heads, ctx.w_dtype = heads, w.dtype
         return y
@@ -1393,7 +1403,9 @@ class HeadContractFn(torch.autograd.Function):
             dw = _per_head_wgrad(dy, xb, heads, hd, Cin)
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
-        return dxb, dw, None
+        if len(ctx.needs_input_grad) < 4:     # called without an addend
+            return dxb, dw, None
+        return dxb, dw, None, (dy if ctx.needs_input_grad[3] else None)
 
 
 def _fill_sva_abs(d, q, kvs, masks, xhat, mask_a, ra, U, bk, bv, B, qside, window_major):
@@ -1476,6 +1488,11 @@ class SvaAbsorbedFn(torch.autograd.Function):
         return (dq, dU, dbk, dbv, dxhat, None, None, None, None, None, None, *dkvs)
 
 
+# CAMBRIAN_AMD_FUSE_CONTRACT_ADD=1: the one-key towers' output is added to the windowed tower's W_v Xb inside the per-head GEMM's
+# epilogue (a batched residual) instead of by an ATen add over [Bq, 1024].  Measured neutral (profiles/r06_lab.md section 25): off.
+FUSE_CONTRACT_ADD = os.environ.get("CAMBRIAN_AMD_FUSE_CONTRACT_ADD", "0") == "1"
+
+
 def sva_absorbed_attention(qh, kvs_direct, masks_direct, xhat, mask_a, ra: int, wk, bk, wv, bv, B: int, qside: int,
                            window_major: bool = False) -> torch.Tensor:
     """The SVA attention core with the windowed tower's K / V projections absorbed (csrc/sva_absorbed.hip): ``qh`` [Bq, 1024]
@@ -1485,6 +1502,8 @@ def sva_absorbed_attention(qh, kvs_direct, masks_direct, xhat, mask_a, ra: int, 
     rows ``xhat @ [wk; wv]^T + [bk; bv]``."""
     U = HeadExpandFn.apply(qh, wk, 16)                                           # [Bq, 16, 1024]
     out_d, xbar, _ = SvaAbsorbedFn.apply(qh, U, bk, bv, xhat, B, qside, ra, list(masks_direct), mask_a, window_major, *kvs_direct)
+    if FUSE_CONTRACT_ADD:
+        return HeadContractFn.apply(xbar, wv, 16, out_d)                          # out_d + W_v,h Xb, added in the GEMM's epilogue
     return out_d + HeadContractFn.apply(xbar, wv, 16)                             # + W_v,h Xb
 
 

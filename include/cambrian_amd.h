@@ -145,7 +145,8 @@ typedef struct cmb_gemm_desc {
   int32_t batch;           /* > 1: `batch` independent problems of this shape in one launch (the sixteen per-head GEMMs of
                               the absorbed SVA projections, vision_sampler.py:187-189 restated per head): problem z uses
                               A + z * a_batch_stride, B + z * b_batch_stride, C + z * c_batch_stride (elements; 16-byte
-                              multiples).  bf16 / fp32, 128x128 tile, no bias / colscale / residual / pre_out / split-K */
+                              multiples).  bf16 / fp32, 128x128 tile, no bias / colscale / pre_out / split-K; a residual (operand dtype)
+                              is laid out as C: problem z adds residual + z * c_batch_stride through r_map */
   int64_t a_batch_stride, b_batch_stride, c_batch_stride;
   /* LayerNorm folded into the linear that follows it (round 6; the frozen towers' LN -> qkv / fc1 pairs: HF / timm blocks behind
    * clip_encoder.py:104, siglip_encoder.py:97, dino_encoder.py:159, clip_convnext_encoder.py:133-136):

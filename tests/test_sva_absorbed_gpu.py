@@ -42,6 +42,14 @@ def test_batched_head_gemms_match_einsum(dev):
     y.backward(gy)
     assert rel_err(xb.grad, torch.einsum("qhj,hjc->qhc", gy.float().view(Bq, H, hd), w2r.view(H, hd, Cin))) < 1e-2
     assert rel_err(w2.grad, torch.einsum("qhj,qhc->hjc", gy.float().view(Bq, H, hd), xb.detach().float()).reshape(H * hd, Cin)) < 1e-2
+    # with an addend: y = addend + the per-head products inside the GEMM's epilogue (one rounding); its gradient is dy itself
+    add = torch.randn(Bq, H * hd, generator=g).to(dt).to(dev).requires_grad_()
+    xb2 = xb.detach().clone().requires_grad_()
+    y2 = ops.HeadContractFn.apply(xb2, w2, H, add)
+    assert rel_err(y2, yref + add.detach().float()) < 1e-2
+    assert rel_err(y2.float(), y.detach().float() + add.detach().float()) < 8e-3      # against the two-step form: bf16 rounding
+    y2.backward(gy)
+    assert torch.equal(add.grad, gy) and torch.equal(xb2.grad, xb.grad)
 
 
 def _case(dev, B, qside, ra, nsmall, window_major, seed, dt=torch.bfloat16):
